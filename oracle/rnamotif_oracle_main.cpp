@@ -1,0 +1,92 @@
+/*
+ * rnamotif_oracle_main.cpp -- TEST INFRASTRUCTURE (see rm_oracle.h).
+ *
+ * A test-only `rnamotif` executable: the product's host front end (descriptor
+ * compiler, score VM, driver) wired to the scalar CPU oracle instead of the
+ * HIP scanner.  It exists to pin the front end + oracle against the
+ * reference's golden outputs in a container that has no GPU, and as the
+ * cpu_baseline leg of bench.py.  It is never installed or loaded by the
+ * package.
+ */
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#include "rm_cli.h"
+#include "rm_oracle.h"
+
+namespace {
+
+struct OracleBackend {
+	const rma_program_t	*prog;
+	const rma_efndata_t	*efn;
+	rma_efndata_t	own_efn;
+	rmo_hits_t	hits;
+	std::vector<int32_t>	sorted;
+};
+
+int oracle_scan( void *self, const char *const *seqs, const int32_t *slens, int n,
+	const int32_t **hits, int64_t *n_hits, char *err, size_t errlen )
+{
+	OracleBackend	*ob = ( OracleBackend * )self;
+	rmo_hits_free( &ob->hits );
+	rmo_hits_init( &ob->hits, ob->prog );
+	std::vector<char>	buf;
+	for( int s = 0; s < n; s++ ){
+		buf.assign( seqs[ s ], seqs[ s ] + slens[ s ] );
+		buf.push_back( '\0' );
+		if( rmo_scan( ob->prog, ob->efn, s, buf.data(), slens[ s ], 0, &ob->hits ) ){
+			snprintf( err, errlen, "oracle: helix candidate list overflow" );
+			return 1;
+		}
+		if( ob->prog->chk_both_strs ){
+			rmo_revcomp( buf.data(), slens[ s ] );
+			if( rmo_scan( ob->prog, ob->efn, s, buf.data(), slens[ s ], 1, &ob->hits ) ){
+				snprintf( err, errlen, "oracle: helix candidate list overflow" );
+				return 1;
+			}
+		}
+	}
+	// the oracle emits in reference order already; sort anyway through the
+	// boundary's key so the same comparator is exercised as on the device path
+	int	stride = ob->hits.stride;
+	std::vector<int64_t>	idx( ob->hits.n );
+	std::iota( idx.begin(), idx.end(), 0 );
+	const int32_t	*d = ob->hits.data;
+	std::stable_sort( idx.begin(), idx.end(), [&]( int64_t a, int64_t b ){
+		const int32_t	*x = d + a * stride, *y = d + b * stride;
+		for( int k = 0; k < 4; k++ )
+			if( x[ k ] != y[ k ] )
+				return x[ k ] < y[ k ];
+		return false;
+	} );
+	ob->sorted.resize( size_t( ob->hits.n ) * stride );
+	for( int64_t i = 0; i < ob->hits.n; i++ )
+		memcpy( &ob->sorted[ i * stride ], d + idx[ i ] * stride, stride * sizeof( int32_t ) );
+	*hits = ob->sorted.data();
+	*n_hits = ob->hits.n;
+	return 0;
+}
+
+rma::ScanBackend make_oracle( const rma_program_t *prog, const rma_efndata_t *efn )
+{
+	OracleBackend	*ob = new OracleBackend;
+	ob->prog = prog;
+	ob->efn = efn;
+	// the oracle reads the tables with its own loader when told where they are
+	const char	*dir = getenv( "RMO_EFNDATA" );
+	if( efn != nullptr && dir != nullptr ){
+		if( !rmo_load_efndata( dir, &ob->own_efn ) )
+			rma::fail( "oracle: can't load efn data from %s", dir );
+		ob->efn = &ob->own_efn;
+	}
+	rmo_hits_init( &ob->hits, prog );
+	return rma::ScanBackend{ ob, oracle_scan };
+}
+
+}	// namespace
+
+int main( int argc, char **argv )
+{
+	return rma::cli_main( argc, argv, make_oracle );
+}

@@ -1,0 +1,80 @@
+// rm_cli.cpp -- see rm_cli.h.
+#include "rm_cli.h"
+#include "rm_score.h"
+#include "rm_efndata.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace rma {
+
+Prepared prepare( const Args &args )
+{
+	Prepared	pr;
+	pr.descr = compile_descriptor( args );
+	Descriptor	&d = *pr.descr;
+	d.score->linkscore();
+	pr.prog.reset( new rma_program_t );
+	d.to_program( pr.prog.get() );
+	const std::vector<EfnCall>	&ec = d.score->efn_calls();
+	if( ec.size() > RMA_MAX_EFN_SITES )
+		fail( "more than %d efn() calls in the score section.", RMA_MAX_EFN_SITES );
+	pr.prog->n_efn_sites = int( ec.size() );
+	for( size_t k = 0; k < ec.size(); k++ )
+		pr.prog->efn_sites[ k ] = ec[ k ].site;
+	if( !ec.empty() && !args.copt ){
+		pr.efn.reset( new rma_efndata_t );
+		std::string	err, dir = find_efndata_dir( d );
+		if( !load_efndata( dir, pr.efn.get(), err ) ){
+			// score.c:1593: rm_efndataok = 0; the reference goes on and
+			// scores with whatever was read.  Report and continue likewise.
+			fputs( err.c_str(), stderr );
+		}
+	}
+	return pr;
+}
+
+int cli_main( int argc, char **argv, BackendFactory make_backend )
+{
+	try{
+		Args	args = parse_args( argc, argv );
+		if( args.vopt && !args.sopt ){
+			fprintf( stderr, "%s: %s.\n", argv[ 0 ], VERSION_STR );
+			return 0;
+		}
+		if( !args.have_dfname && !args.have_xdfname ){
+			fprintf( stderr, USAGE_FMT, argv[ 0 ] );
+			return 1;
+		}
+		Prepared	pr = prepare( args );
+		Descriptor	&d = *pr.descr;
+		if( !d.stderr_text.empty() ){
+			fputs( d.stderr_text.c_str(), stderr );
+			d.stderr_text.clear();
+		}
+		if( args.have_dfname ){		// rnamot.c:89-97
+			fprintf( stderr, "%s: complete descr length: min/max = %d/", args.dfname.c_str(), d.dminlen );
+			if( d.dmaxlen == UNBOUNDED )
+				fprintf( stderr, "UNBND\n" );
+			else
+				fprintf( stderr, "%d\n", d.dmaxlen );
+		}
+		if( args.dopt || args.popt )
+			d.score->dump( stderr );
+		if( args.copt )
+			return 0;
+		ScanBackend	be = make_backend( pr.prog.get(), pr.efn.get() );
+		const char	*bb = getenv( "RNAMOTIF_BATCH_BASES" );
+		int64_t	batch_bases = bb ? atoll( bb ) : ( int64_t( 1 ) << 28 );
+		run_search( d, *pr.prog, be, stdout, batch_bases, nullptr );
+		return 0;
+	}catch( Error &e ){
+		const char	*m = e.what();
+		fputs( m, stderr );
+		size_t	n = strlen( m );
+		if( n == 0 || m[ n - 1 ] != '\n' )
+			fputc( '\n', stderr );
+		return 1;
+	}
+}
+
+}	// namespace rma

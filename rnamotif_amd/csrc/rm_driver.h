@@ -1,0 +1,46 @@
+// rm_driver.h -- the per-database search loop of the reference's main()
+// (/root/reference/src/rnamot.c:100-190) around a pluggable scanner: read
+// FASTA records, hand batches to the scanner, replay every reported candidate
+// through the score program and print_match() in the reference's order.
+#pragma once
+#include <cstdio>
+#include "rm_host.h"
+#include "rm_fasta.h"
+#include "rm_score.h"
+
+namespace rma {
+
+// What the driver needs from a scanner: scan n sequences (both strands when
+// the program says so) and return hit records sorted by (seq,comp,szero,order).
+// The product binary plugs the HIP scanner in here (rm_capi.cpp).
+struct ScanBackend {
+	void	*self;
+	int	( *scan )( void *self, const char *const *seqs, const int32_t *slens, int n,
+			const int32_t **hits, int64_t *n_hits, char *err, size_t errlen );
+};
+
+struct SearchStats {
+	int64_t	n_seqs = 0, n_bases = 0, n_candidates = 0, n_hits = 0;
+};
+
+// Replays candidates of one batch.  Exposed for the C-ABI.
+class Replayer {
+public:
+	Replayer( Descriptor &d, const rma_program_t &prog, FILE *out );
+	void	begin();		// BEGIN program, rnamot.c:154-155
+	void	end();			// END program, rnamot.c:187-188
+	// hits: n records of stride rma_hit_stride( prog ), sorted
+	void	replay( const std::vector<SeqRecord> &batch, const int32_t *hits, int64_t n, SearchStats &st );
+private:
+	Descriptor	&d_;
+	const rma_program_t	&prog_;
+	FILE	*out_;
+	HitPrinter	printer_;
+};
+
+// rnamot.c:125-190.  batch_bases bounds how much sequence is handed to the
+// scanner at once.
+int	run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE *out,
+		int64_t batch_bases, SearchStats *stats );
+
+}	// namespace rma

@@ -1,0 +1,42 @@
+// rm_fasta.h -- sequence database reader (FASTA) and the 2-bit + ambiguity
+// mask packing the scanner keeps in HBM.  Record parsing follows FN_fgetseq,
+// /root/reference/src/dbutil.c:42-128.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace rma {
+
+struct SeqRecord {
+	std::string	sid, sdef;
+	std::string	seq;		// lower case, u -> t, every alpha kept
+	bool	eof = false;		// FN_fgetseq returned EOF (no record)
+};
+
+class FastaReader {
+public:
+	explicit FastaReader( FILE *fp, int maxslen = 30000001 ) : fp_( fp ), maxslen_( maxslen ) {}
+	// returns false at end of file; diagnostics go to stderr like the reference
+	bool	next( SeqRecord &rec );
+private:
+	FILE	*fp_;
+	int	maxslen_;
+};
+
+// Packed database layout (device side):
+//   codes: 2 bits per base, 16 bases per uint32 word, base i of a sequence at
+//          bits 2*(i%16) of word i/16; a=0 c=1 g=2 t=3, ambiguous letters 0
+//   amask: 1 bit per base, 32 per uint32; set for every letter that is not acgt
+// Each sequence starts on a word boundary of both arrays (32-base aligned).
+struct PackedDb {
+	std::vector<uint32_t>	codes, amask;
+	std::vector<int64_t>	base_off;	// per sequence: offset in bases (multiple of 32)
+	std::vector<int32_t>	slen;
+	int64_t	total_bases = 0;		// sum of slen
+	void	add( const char *seq, int slen );
+	int64_t	padded_bases() const { return int64_t( amask.size() ) * 32; }
+};
+
+}	// namespace rma
