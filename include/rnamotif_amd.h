@@ -1,0 +1,91 @@
+/*
+ * rnamotif_amd.h -- C ABI of the MI355X scan path.
+ *
+ * The reference has no plug-in API; the boundary this library replaces is the
+ * set of calls main() makes around the scan (/root/reference/src/rnamot.c:49-188,
+ * prototypes in /root/reference/src/rnamot.h:305-381):
+ *
+ *   RM_init() + yyparse() + SE_link() + RM_linkscore()   -> rma_descr_compile()
+ *   RM_fm_init()                  (find_motif.c:109)      -> rma_scanner_create()
+ *   FN_fgetseq() into sbuf        (dbutil.c:42)           -> rma_db_create()
+ *   RM_find_motif() x2 per entry  (find_motif.c:164)      -> rma_scan()
+ *   RM_score() + print_match()    (score.c:608,
+ *                                  find_motif.c:1826)     -> rma_replay_*()
+ *
+ * Plain C: pointers, sizes, integer status codes.  Every function that can
+ * fail returns 0 on success and non-zero with a message in err[] otherwise;
+ * nothing in the library calls exit().  The scan runs on the GPU only: there is
+ * no CPU fallback, rma_scanner_create() fails when no HIP device is usable.
+ */
+#ifndef RNAMOTIF_AMD_H
+#define RNAMOTIF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rnamotif_amd_program.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rma_descr	rma_descr_t;	/* compiled descriptor + score program (host)	*/
+typedef struct rma_scanner	rma_scanner_t;	/* motif program + buffers on one GPU		*/
+typedef struct rma_db		rma_db_t;	/* packed sequences resident in HBM		*/
+typedef struct rma_replay	rma_replay_t;	/* score VM + hit printer state			*/
+
+const char	*rma_version( void );
+int	rma_device_count( void );
+
+/* ---- descriptor front end (host).  argv is the rnamotif command line
+ * (argv[0] = program name, "-descr file", "-Dname=value", "-sh", "-context", ...);
+ * database file names in it are remembered for rma_descr_dbfiles(). */
+int	rma_descr_compile( int argc, const char *const *argv, rma_descr_t **out, char *err, size_t errlen );
+void	rma_descr_free( rma_descr_t *d );
+const rma_program_t	*rma_descr_program( const rma_descr_t *d );
+const rma_efndata_t	*rma_descr_efndata( const rma_descr_t *d );	/* NULL: no efn() in the score section */
+int	rma_descr_minlen( const rma_descr_t *d );			/* rm_dminlen */
+int	rma_descr_maxlen( const rma_descr_t *d );			/* rm_dmaxlen, RMA_UNBOUNDED if open */
+/* for bindings that do not want to mirror the struct: n_elems, n_searches, hit stride,
+ * ctx offset, efn offset, n_efn_sites, chk_both_strs, windowsize */
+void	rma_program_info( const rma_program_t *prog, int32_t info[ 8 ] );
+
+/* ---- scanner.  prog (and efn, may be NULL) are copied. */
+int	rma_scanner_create( const rma_program_t *prog, const rma_efndata_t *efn, int device,
+		rma_scanner_t **out, char *err, size_t errlen );
+void	rma_scanner_destroy( rma_scanner_t *sc );
+
+/* ---- database: n sequences of lower case letters as the reference's readers
+ * deliver them (dbutil.c: every alpha character kept, u -> t).  They are packed
+ * 2 bits + 1 ambiguity bit per base and uploaded; the host text is not kept. */
+int	rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
+		rma_db_t **out, char *err, size_t errlen );
+void	rma_db_destroy( rma_db_t *db );
+int64_t	rma_db_bases( const rma_db_t *db );
+
+/* ---- scan every sequence of db (both strands when the program says so).
+ * *hits receives *n_hits records of rma_hit_stride( prog ) words, sorted by
+ * (seq, comp, szero, rank, order) = the reference's output order; the memory
+ * belongs to the scanner and is valid until its next scan or destruction.
+ * Energies of the program's efn sites are filled in. */
+int	rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **hits, int64_t *n_hits,
+		char *err, size_t errlen );
+
+/* The device part of rma_scan() alone (search kernel + efn kernel, no copy back,
+ * no sort), for measurement: returns the candidate count and the time of the
+ * search kernel as measured with HIP events on the scanner's stream. */
+int	rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
+		float *efn_ms, char *err, size_t errlen );
+
+/* ---- replay: run the score program over candidates and print accepted hits
+ * in the reference's format to a stdio stream opened on path ("-" = stdout). */
+int	rma_replay_open( rma_descr_t *d, const char *path, rma_replay_t **out, char *err, size_t errlen );
+/* one batch: the same sequences (ids, definition lines, text) the db was made from */
+int	rma_replay_batch( rma_replay_t *rp, const char *const *sids, const char *const *sdefs,
+		const char *const *seqs, const int32_t *slens, int32_t n,
+		const int32_t *hits, int64_t n_hits, int64_t *n_printed, char *err, size_t errlen );
+int	rma_replay_close( rma_replay_t *rp, char *err, size_t errlen );	/* runs the END program */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -185,14 +185,17 @@ typedef struct rma_efndata {
  *   [0] seq     index of the sequence in the batch
  *   [1] comp    0 = strand as given, 1 = reverse complement
  *   [2] szero   start offset of the scan position (fm_szero)
- *   [3] order   emission counter of this hit within (seq,comp,szero); hits
- *               sorted by (seq,comp,szero,order) are in the reference's
- *               output order (find_motif.c:184-205,273,435,523,600,821,938)
- *   [4 + 4*e .. ] per element e: matchoff, matchlen, n_mispairs, n_mismatches
+ *   [3] rank    which end position of the first search element this hit
+ *               came from: 0 for the largest (tried first), counting up
+ *               (find_motif.c:273 loops sdollar downwards)
+ *   [4] order   emission counter within (seq,comp,szero,rank); hits sorted
+ *               by (seq,comp,szero,rank,order) are in the reference's output
+ *               order (find_motif.c:184-205,273,435,523,600,821,938)
+ *   [5 + 4*e .. ] per element e: matchoff, matchlen, n_mispairs, n_mismatches
  *   then lctx off,len, rctx off,len (0,0 when absent)
  *   then one word per efn site: energy in 1/100 kcal/mol (RM_efn's int)
  */
-#define RMA_HIT_HDR	4
+#define RMA_HIT_HDR	5
 static inline int rma_hit_stride( const rma_program_t *p )
 {
 	return( RMA_HIT_HDR + 4 * p->n_elems + 4 + p->n_efn_sites );

@@ -38,7 +38,7 @@ typedef struct ctx_t {
 	int	l_off, l_len, r_off, r_len;	/* rm_lctx / rm_rctx match	*/
 	int	l_mm, r_mm;
 	int	*winbuf, *window;		/* fm_winbuf / fm_window	*/
-	int	order;
+	int	rank, order;
 	rmo_hits_t	*hits;
 	int	err;
 	int	b2bc[ 256 ];
@@ -732,7 +732,8 @@ static	void	emit_hit( ctx_t *c )	/* find_ss :373-392 up to RM_score() */
 	w[ 0 ] = c->seq;
 	w[ 1 ] = c->comp;
 	w[ 2 ] = c->szero;
-	w[ 3 ] = c->order++;
+	w[ 3 ] = c->rank;
+	w[ 4 ] = c->order++;
 	for( d = 0; d < p->n_elems; d++ ){
 		w[ RMA_HIT_HDR + 4 * d + 0 ] = c->moff[ d ];
 		w[ RMA_HIT_HDR + 4 * d + 1 ] = c->mlen[ d ];
@@ -1185,6 +1186,10 @@ static	int	find_motif( ctx_t *c, int s )	/* :245 */
 	l_sdollar = c->zero[ s ] + stp->minglen - 1;
 	if( loop ){
 		for( sdollar = f_sdollar; sdollar >= l_sdollar; sdollar-- ){
+			if( s == 0 ){		/* boundary sort key, not in the reference */
+				c->rank = f_sdollar - sdollar;
+				c->order = 0;
+			}
 			c->dollar[ s ] = sdollar;
 			if( n_s >= 0 ){
 				c->zero[ n_s ] = sdollar + 1;
@@ -1267,7 +1272,6 @@ int	rmo_scan( const rma_program_t *p, const rma_efndata_t *ed, int seq_index,
 	l_szero = slen - w_winsize;
 	for( szero = 0; szero < l_szero && !c->err; szero++ ){
 		c->szero = szero;
-		c->order = 0;
 		c->zero[ 0 ] = szero;
 		c->dollar[ 0 ] = MIN( szero + w_winsize - 1, slen - 1 );
 		c->window[ -1 ] = UNDEF;
@@ -1278,7 +1282,6 @@ int	rmo_scan( const rma_program_t *p, const rma_efndata_t *ed, int seq_index,
 	c->dollar[ 0 ] = slen - 1;
 	for( ; szero <= l_szero && !c->err; szero++ ){
 		c->szero = szero;
-		c->order = 0;
 		c->zero[ 0 ] = szero;
 		find_motif( c, 0 );
 	}

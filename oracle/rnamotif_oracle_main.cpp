@@ -55,7 +55,7 @@ int oracle_scan( void *self, const char *const *seqs, const int32_t *slens, int 
 	const int32_t	*d = ob->hits.data;
 	std::stable_sort( idx.begin(), idx.end(), [&]( int64_t a, int64_t b ){
 		const int32_t	*x = d + a * stride, *y = d + b * stride;
-		for( int k = 0; k < 4; k++ )
+		for( int k = 0; k < RMA_HIT_HDR; k++ )
 			if( x[ k ] != y[ k ] )
 				return x[ k ] < y[ k ];
 		return false;

@@ -1,0 +1,270 @@
+"""rnamotif_amd -- MI355X-native scan path of rnamotif behind a C ABI.
+
+Thin ctypes mirror of include/rnamotif_amd.h.  The work is done by
+``librnamotif_amd.so`` (host front end in C++, search and efn kernels in HIP for
+gfx950); this module only moves pointers.  There is no CPU implementation of the
+scan in this package: if the library is missing or no GPU is usable the calls
+fail loudly.
+
+Reference boundary (see the header for the full table):
+  rma_descr_compile  <- RM_init/yyparse/SE_link/RM_linkscore (rnamot.c:49-98)
+  rma_scanner_create <- RM_fm_init (find_motif.c:109)
+  rma_scan           <- RM_find_motif (find_motif.c:164), both strands
+  rma_replay_*       <- RM_score + print_match (score.c:608, find_motif.c:1826)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnamotif_amd.so")
+EFNDATA_DIR = os.path.join(_HERE, "efndata")
+CLI_PATH = os.path.join(_HERE, "bin", "rnamotif")
+
+RMA_HIT_HDR = 5
+_ERRLEN = 4096
+
+
+class RnamotifError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librnamotif_amd.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RnamotifError(
+            f"{LIB_PATH} is missing: build it with `make -C rnamotif_amd/csrc` "
+            "(hipcc --offload-arch=gfx950); there is no fallback implementation")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, i64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    cpp = C.POINTER(C.c_char_p)
+    L.rma_version.restype = C.c_char_p
+    L.rma_device_count.restype = C.c_int
+    L.rma_descr_compile.argtypes = [C.c_int, cpp, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_descr_free.argtypes = [vp]
+    L.rma_descr_program.argtypes = [vp]
+    L.rma_descr_program.restype = vp
+    L.rma_descr_efndata.argtypes = [vp]
+    L.rma_descr_efndata.restype = vp
+    L.rma_descr_minlen.argtypes = [vp]
+    L.rma_descr_maxlen.argtypes = [vp]
+    L.rma_program_info.argtypes = [vp, i32p]
+    L.rma_program_info.restype = None
+    L.rma_scanner_create.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_scanner_destroy.argtypes = [vp]
+    L.rma_db_create.argtypes = [vp, cpp, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_db_destroy.argtypes = [vp]
+    L.rma_db_bases.argtypes = [vp]
+    L.rma_db_bases.restype = C.c_int64
+    L.rma_scan.argtypes = [vp, vp, C.POINTER(i32p), i64p, C.c_char_p, C.c_size_t]
+    L.rma_scan_device.argtypes = [vp, vp, i64p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                  C.c_char_p, C.c_size_t]
+    L.rma_replay_open.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_replay_batch.argtypes = [vp, cpp, cpp, cpp, i32p, C.c_int32, i32p, C.c_int64, i64p,
+                                   C.c_char_p, C.c_size_t]
+    L.rma_replay_close.argtypes = [vp, C.c_char_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _check(rc: int, err) -> None:
+    if rc != 0:
+        raise RnamotifError(err.value.decode("utf-8", "replace").rstrip())
+
+
+def _cstr_array(items: Sequence[bytes]):
+    arr = (C.c_char_p * max(len(items), 1))()
+    for i, s in enumerate(items):
+        arr[i] = s
+    return arr
+
+
+class Descriptor:
+    """A compiled descriptor: ``Descriptor(["-descr", "trna.descr"])``.
+
+    ``argv`` is the rnamotif command line without the program name.  For
+    descriptors whose score section calls efn() the energy tables are read from
+    ``efn_datadir`` / $EFNDATA as in the reference; $EFNDATA defaults to the
+    tables shipped with the package.
+    """
+
+    def __init__(self, argv: Sequence[str]):
+        os.environ.setdefault("EFNDATA", EFNDATA_DIR)
+        L = lib()
+        args = [b"rnamotif"] + [a.encode() for a in argv]
+        arr = _cstr_array(args)
+        h = C.c_void_p()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_descr_compile(len(args), arr, C.byref(h), err, _ERRLEN), err)
+        self._h = h
+        self.program = L.rma_descr_program(h)
+        self.efndata = L.rma_descr_efndata(h)
+        info = (C.c_int32 * 8)()
+        L.rma_program_info(self.program, info)
+        (self.n_elems, self.n_searches, self.hit_stride, self.ctx_off, self.efn_off,
+         self.n_efn_sites, self.both_strands, self.windowsize) = list(info)
+        self.minlen = L.rma_descr_minlen(h)
+        self.maxlen = L.rma_descr_maxlen(h)
+
+    def close(self) -> None:
+        if self._h:
+            lib().rma_descr_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Database:
+    """Sequences packed 2 bit + ambiguity mask, resident in HBM."""
+
+    def __init__(self, scanner: "Scanner", seqs: Sequence[bytes]):
+        L = lib()
+        self.scanner = scanner
+        self.n_seqs = len(seqs)
+        arr = _cstr_array(seqs)
+        lens = (C.c_int32 * max(len(seqs), 1))(*[len(s) for s in seqs])
+        h = C.c_void_p()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_db_create(scanner._h, arr, lens, len(seqs), C.byref(h), err, _ERRLEN), err)
+        self._h = h
+        self.bases = L.rma_db_bases(h)
+
+    def close(self) -> None:
+        if self._h:
+            lib().rma_db_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scanner:
+    """The motif program on one GPU (RM_fm_init + RM_find_motif)."""
+
+    def __init__(self, descr: Descriptor, device: int = 0):
+        L = lib()
+        self.descr = descr
+        h = C.c_void_p()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_scanner_create(descr.program, descr.efndata, device, C.byref(h), err, _ERRLEN), err)
+        self._h = h
+
+    def database(self, seqs: Sequence[bytes]) -> Database:
+        return Database(self, seqs)
+
+    def scan(self, db: Database) -> np.ndarray:
+        """All candidates of db in reference order: int32 array [n, hit_stride]."""
+        L = lib()
+        hits = C.POINTER(C.c_int32)()
+        n = C.c_int64()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_scan(self._h, db._h, C.byref(hits), C.byref(n), err, _ERRLEN), err)
+        stride = self.descr.hit_stride
+        if n.value == 0:
+            return np.zeros((0, stride), dtype=np.int32)
+        a = np.ctypeslib.as_array(hits, shape=(n.value * stride,))
+        return a.reshape(n.value, stride).copy()
+
+    def scan_device(self, db: Database) -> Tuple[int, float, float]:
+        """Device part only: (candidates, search kernel ms, efn kernel ms)."""
+        L = lib()
+        n = C.c_int64()
+        ms1, ms2 = C.c_float(), C.c_float()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_scan_device(self._h, db._h, C.byref(n), C.byref(ms1), C.byref(ms2), err, _ERRLEN), err)
+        return n.value, ms1.value, ms2.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().rma_scanner_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Replay:
+    """Score program + hit printer over candidate records (host side)."""
+
+    def __init__(self, descr: Descriptor, out_path: str = "-"):
+        L = lib()
+        h = C.c_void_p()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_replay_open(descr._h, out_path.encode(), C.byref(h), err, _ERRLEN), err)
+        self._h = h
+
+    def batch(self, sids: Sequence[bytes], sdefs: Sequence[bytes], seqs: Sequence[bytes],
+              hits: np.ndarray) -> int:
+        L = lib()
+        hits = np.ascontiguousarray(hits, dtype=np.int32)
+        lens = (C.c_int32 * max(len(seqs), 1))(*[len(s) for s in seqs])
+        printed = C.c_int64()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_replay_batch(self._h, _cstr_array(sids), _cstr_array(sdefs), _cstr_array(seqs), lens,
+                                  len(seqs), hits.ctypes.data_as(C.POINTER(C.c_int32)), hits.shape[0],
+                                  C.byref(printed), err, _ERRLEN), err)
+        return printed.value
+
+    def close(self) -> None:
+        if self._h:
+            err = C.create_string_buffer(_ERRLEN)
+            rc = lib().rma_replay_close(self._h, err, _ERRLEN)
+            self._h = None
+            _check(rc, err)
+
+
+def read_fasta(path: str) -> List[Tuple[bytes, bytes, bytes]]:
+    """(sid, sdef, seq) per record with the reference reader's normalisation
+    (dbutil.c:42-128: every alpha character kept, lower case, u -> t).  Used by
+    tests and the benchmark; the CLI has its own C++ reader."""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    recs: List[Tuple[bytes, bytes, bytes]] = []
+    sid = sdef = None
+    chunks: List[bytes] = []
+    table = bytes(((c | 0x20) if (65 <= c <= 90) else c) for c in range(256)).replace(b"u", b"t")
+    keep = bytes(c for c in range(256) if chr(c).isalpha() and c < 128)
+    drop = bytes(c for c in range(256) if c not in keep)
+    with op(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if sid is not None:
+                    recs.append((sid, sdef, b"".join(chunks)))
+                hdr = line[1:].strip().split(None, 1)
+                sid = hdr[0] if hdr else b""
+                sdef = hdr[1].rstrip() if len(hdr) > 1 else b""
+                chunks = []
+            else:
+                chunks.append(line.translate(table, drop))
+        if sid is not None:
+            recs.append((sid, sdef, b"".join(chunks)))
+    return recs
+
+
+def synthetic_records(k: int, length: int = 1_000_000, seed: int = 20240601) -> List[bytes]:
+    """BASELINE.md / SURVEY.md section 8d synthetic database: k records of
+    iid uniform acgt from numpy default_rng(seed); the first 10 records of the
+    default parameters are the survey's syn10M."""
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    return [lut[rng.integers(0, 4, size=length)].tobytes() for _ in range(k)]

@@ -1,0 +1,229 @@
+// rm_dev_program.cpp -- reduce the boundary blob to the device form
+// (see rm_dev_program.h).  Host code.
+#include "rm_dev_program.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+const double	EPS = 1e-6;	// find_motif.c:15
+
+bool build_regex( const rma_regex_t &re, rmd_regex_t *out )
+{
+	memset( out, 0, sizeof( *out ) );
+	out->anchored = re.anchored;
+	out->dollar = re.dollar;
+	out->fixed_len = re.fixed_len;
+	int	n = 0, run = 0, longest = 0;
+	auto add = [&]( const rma_re_atom_t &a, bool opt, bool star ) -> bool {
+		if( n >= 63 )
+			return false;
+		for( int c = 0; c < 5; c++ )
+			if( ( a.mask >> c ) & 1 )
+				out->accept[ c ] |= 1ull << n;
+		if( opt ){
+			out->opt |= 1ull << n;
+			run++;
+			longest = std::max( longest, run );
+		}else
+			run = 0;
+		if( star )
+			out->star |= 1ull << n;
+		if( a.kind == 1 )
+			out->dot |= 1ull << n;
+		n++;
+		return true;
+	};
+	for( int i = 0; i < re.n_atoms; i++ ){
+		const rma_re_atom_t	&a = re.atoms[ i ];
+		for( int k = 0; k < a.lo; k++ )
+			if( !add( a, false, false ) )
+				return false;
+		if( a.hi == 255 ){
+			if( !add( a, true, true ) )
+				return false;
+		}else for( int k = a.lo; k < a.hi; k++ )
+			if( !add( a, true, false ) )
+				return false;
+	}
+	out->n_states = n;
+	out->n_close = longest;
+	return true;
+}
+
+}	// namespace
+
+int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t errlen )
+{
+#define FAIL( ... )	do{ snprintf( err, errlen, __VA_ARGS__ ); return -1; }while( 0 )
+	memset( out, 0, sizeof( *out ) );
+	if( p->magic != RMA_MAGIC || p->size != sizeof( rma_program_t ) )
+		FAIL( "not a motif program (bad magic or size)" );
+	if( p->n_elems > RMD_MAX_ELEMS )
+		FAIL( "descriptor has %d elements; the device scanner takes at most %d", p->n_elems, RMD_MAX_ELEMS );
+	if( p->n_sites > RMD_MAX_SITES )
+		FAIL( "descriptor has %d sites; the device scanner takes at most %d", p->n_sites, RMD_MAX_SITES );
+	if( p->n_regexes > RMD_MAX_RE )
+		FAIL( "too many seq= expressions for the device scanner" );
+	out->n_elems = p->n_elems;
+	out->n_searches = p->n_searches;
+	out->dminlen = p->dminlen;
+	out->w_winsize = p->dmaxlen < p->windowsize ? p->dmaxlen : p->windowsize;
+	out->strict_helices = p->strict_helices;
+	out->has_lctx = p->has_lctx;
+	out->has_rctx = p->has_rctx;
+	out->n_sites = p->n_sites;
+	out->n_efn = p->n_efn_sites;
+	out->efn_usestdbp = p->efn_usestdbp;
+	out->hit_stride = rma_hit_stride( p );
+	for( int s = 0; s < p->n_searches; s++ )
+		out->searches[ s ] = int8_t( p->searches[ s ] );
+
+	// pair sets: identical tables share a slot
+	int	n_ps = 0;
+	int	psmap[ RMA_MAX_PAIRSETS ];
+	for( int i = 0; i < p->n_pairsets; i++ ){
+		rmd_pairset_t	d;
+		d.mat2 = p->pairsets[ i ].mat2;
+		memcpy( d.mat3, p->pairsets[ i ].mat3, sizeof( d.mat3 ) );
+		memcpy( d.mat4, p->pairsets[ i ].mat4, sizeof( d.mat4 ) );
+		int	k;
+		for( k = 0; k < n_ps; k++ )
+			if( !memcmp( &out->pairsets[ k ], &d, sizeof( d ) ) )
+				break;
+		if( k == n_ps ){
+			if( n_ps == RMD_MAX_PS )
+				FAIL( "too many distinct pair sets for the device scanner" );
+			out->pairsets[ n_ps++ ] = d;
+		}
+		psmap[ i ] = k;
+	}
+	out->efn_stdbp = p->efn_stdbp >= 0 ? psmap[ p->efn_stdbp ] : 0;
+
+	for( int i = 0; i < p->n_regexes; i++ )
+		if( !build_regex( p->regexes[ i ], &out->regexes[ i ] ) )
+			FAIL( "a seq= expression expands to more than 63 positions" );
+
+	auto cvt = [&]( const rma_elem_t &e, rmd_elem_t *d ) -> int {
+		d->type = int8_t( e.type );
+		d->proper = int8_t( e.proper );
+		d->ends = int8_t( e.ends );
+		d->strict = int8_t( e.strict );
+		d->loop = e.next >= 0 || e.outer < 0;
+		d->next_s = e.next >= 0 ? int8_t( p->elems[ e.next ].searchno ) : -1;
+		d->inner = int8_t( e.inner );
+		d->inner_s = e.inner >= 0 ? int8_t( p->elems[ e.inner ].searchno ) : -1;
+		d->searchno = int8_t( e.searchno );
+		d->n_mates = int8_t( e.n_mates );
+		for( int m = 0; m < 3; m++ )
+			d->mates[ m ] = int8_t( e.mates[ m ] );
+		d->n_scopes = int8_t( e.n_scopes );
+		d->scope = int8_t( e.scope );
+		for( int s = 0; s < 8; s++ )
+			d->scopes[ s ] = int8_t( e.scopes[ s ] );
+		d->pairset = e.pairset >= 0 ? int8_t( psmap[ e.pairset ] ) : -1;
+		d->re = int8_t( e.re );
+		d->minlen = e.minlen;
+		d->maxlen = e.maxlen;
+		d->minglen = e.minglen;
+		d->maxglen = e.maxglen;
+		d->minilen = e.minilen;
+		d->maxilen = e.maxilen;
+		d->mismatch = e.mismatch;
+		// every strand of a helix carries the group's rules (match_4plex reads them from q2)
+		bool	helix = e.type != RMA_T_SS && e.type != RMA_T_CTX;
+		if( helix ){
+			if( e.maxlen > RMD_MAX_HLEN )
+				return 1;
+			// find_motif.c:1023-1033
+			if( e.mispair > 0 ){
+				d->mplim = e.mispair;
+				d->pfrac = 0;
+			}else if( e.pairfrac < 1.0 ){
+				d->mplim = int( ( 1. - e.pairfrac ) * std::min( e.maxlen, p->windowsize ) + 0.5 );
+				d->pfrac = 1;
+			}else{
+				d->mplim = 0;
+				d->pfrac = 0;
+			}
+			for( int hl = 0; hl <= RMD_MAX_HLEN; hl++ ){
+				int	best = 0;
+				if( hl == 0 )
+					best = 255;
+				else for( int mpr = 0; mpr <= hl; mpr++ ){
+					if( !( 1. * ( hl - mpr ) / hl < e.pairfrac - EPS ) )	// :1040,:1086
+						best = mpr;
+				}
+				d->pf_maxmpr[ hl ] = uint8_t( best );
+				int	tq = 0;		// :1190-1194, :1241-1245
+				if( e.mispair > 0 )
+					tq = e.mispair;
+				else if( e.pairfrac < 1.0 )
+					tq = int( ( 1. - e.pairfrac ) * hl + 0.5 );
+				d->tq_mplim[ hl ] = uint8_t( std::min( tq, 255 ) );
+			}
+		}
+		return 0;
+	};
+	for( int i = 0; i < p->n_elems; i++ ){
+		if( cvt( p->elems[ i ], &out->elems[ i ] ) )
+			FAIL( "helix element %d allows %d base pairs; the device scanner takes at most %d",
+				i + 1, p->elems[ i ].maxlen, RMD_MAX_HLEN );
+	}
+	if( p->has_lctx )
+		cvt( p->lctx, &out->lctx );
+	if( p->has_rctx )
+		cvt( p->rctx, &out->rctx );
+
+	// structure the search relies on (the reference dereferences these unchecked)
+	if( p->n_searches < 1 || p->elems[ p->searches[ p->n_searches - 1 ] ].type != RMA_T_SS )
+		FAIL( "the last element searched must be an ss element" );
+	for( int s = 0; s < p->n_searches; s++ ){
+		const rma_elem_t	&e = p->elems[ p->searches[ s ] ];
+		switch( e.type ){
+		case RMA_T_SS :
+			break;
+		case RMA_T_H5 :
+			if( e.proper && e.inner < 0 )
+				FAIL( "helix element %d has no interior", e.index + 1 );
+			if( !e.proper && ( e.n_scopes < 2 || e.n_scopes > 8 ) )
+				FAIL( "pseudoknot with %d strands is not supported", e.n_scopes );
+			break;
+		case RMA_T_P5 :
+			if( e.inner < 0 )
+				FAIL( "helix element %d has no interior", e.index + 1 );
+			break;
+		case RMA_T_T1 :
+			if( e.inner < 0 || p->elems[ e.scopes[ 1 ] ].inner < 0 )
+				FAIL( "triplex element %d has an empty interior", e.index + 1 );
+			break;
+		case RMA_T_Q1 :
+			if( e.inner < 0 || p->elems[ e.mates[ 0 ] ].inner < 0 || p->elems[ e.mates[ 1 ] ].inner < 0 )
+				FAIL( "4-plex element %d has an empty interior", e.index + 1 );
+			break;
+		default :
+			FAIL( "element %d cannot head a search", e.index + 1 );
+		}
+	}
+	for( int s = 0; s < p->n_sites; s++ ){
+		rmd_site_t	*d = &out->sites[ s ];
+		d->n_pos = int8_t( p->sites[ s ].n_pos );
+		d->pairset = int8_t( psmap[ p->sites[ s ].pairset ] );
+		for( int k = 0; k < 4; k++ ){
+			d->elem[ k ] = int8_t( p->sites[ s ].pos[ k ].elem );
+			d->l2r[ k ] = int8_t( p->sites[ s ].pos[ k ].l2r );
+			d->offset[ k ] = int16_t( p->sites[ s ].pos[ k ].offset );
+		}
+	}
+	for( int k = 0; k < p->n_efn_sites; k++ )
+		out->efn_sites[ k ] = p->efn_sites[ k ];
+	out->lmargin = 1;
+	out->rmargin = 1;
+	if( p->has_lctx && p->lctx.re >= 0 )
+		out->lmargin = std::max( 1, p->lctx.maxlen );
+	if( p->has_rctx && p->rctx.re >= 0 )
+		out->rmargin = std::max( 1, 2 * p->rctx.maxlen );
+	return 0;
+#undef FAIL
+}

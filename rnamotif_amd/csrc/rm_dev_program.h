@@ -1,0 +1,85 @@
+// rm_dev_program.h -- the motif program in the form the scan kernel reads.
+//
+// rma_program_t (include/rnamotif_amd_program.h) is the boundary blob; this is
+// the same information reduced for the device: element table indexed by small
+// integers, pair tables as bit sets, seq= constraints as bit-parallel position
+// automata, the floating point parts of the helix rules folded into integer
+// tables on the host (find_motif.c:1023-1033,1040,1086,1194,1245).  It is small
+// enough to be copied into LDS by every workgroup.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include "rnamotif_amd_program.h"
+
+#define RMD_MAX_ELEMS	32	// elements (and search levels) per descriptor on the device
+#define RMD_MAX_HLEN	63	// longest helix strand: candidate sets are 64-bit masks
+#define RMD_MAX_RE	34
+#define RMD_MAX_PS	40
+#define RMD_MAX_SITES	8
+#define RMD_MAX_EFN	8
+
+// position automaton of one seq= expression: state i (bit i) accepts one base
+struct rmd_regex_t {
+	uint64_t	accept[ 5 ];	// accept[c]: states that take base code c
+	uint64_t	opt;		// states that may be skipped
+	uint64_t	star;		// states that may repeat
+	uint64_t	dot;		// states that came from '.', for the mismatch counter
+	int32_t	n_states;
+	int32_t	n_close;		// longest run of skippable states
+	int32_t	anchored, dollar;
+	int32_t	fixed_len;		// >= 0: every state mandatory (mismatch mode legal)
+};
+
+struct rmd_pairset_t {
+	uint32_t	mat2;
+	uint32_t	mat3[ 4 ];
+	uint32_t	mat4[ 20 ];
+};
+
+struct rmd_elem_t {
+	int8_t	type, proper, ends, strict;
+	int8_t	loop;			// find_motif: iterate over the end position
+	int8_t	next_s;			// search level of s_next, or -1
+	int8_t	inner_s;		// search level of s_inner, or -1
+	int8_t	searchno;
+	int8_t	inner;			// element index of s_inner, or -1
+	int8_t	n_mates, n_scopes, scope;
+	int8_t	mates[ 3 ];
+	int8_t	scopes[ 8 ];
+	int8_t	pairset, re;
+	int8_t	pfrac;			// pairfrac rule active
+	int8_t	pad;
+	int32_t	minlen, maxlen, minglen, maxglen, minilen, maxilen;
+	int32_t	mismatch;
+	int32_t	mplim;			// match_wchlx/match_phlx mispair limit
+	uint8_t	pf_maxmpr[ RMD_MAX_HLEN + 1 ];	// pairfrac test: most mispairs allowed at length hl
+	uint8_t	tq_mplim[ RMD_MAX_HLEN + 1 ];	// match_triplex/match_4plex limit at length tlen
+};
+
+struct rmd_site_t {
+	int8_t	n_pos, pairset;
+	int8_t	elem[ 4 ], l2r[ 4 ];
+	int16_t	offset[ 4 ];
+};
+
+struct rmd_program_t {
+	int32_t	n_elems, n_searches;
+	int32_t	dminlen, w_winsize;	// min( dmaxlen, windowsize )
+	int32_t	strict_helices;
+	int32_t	has_lctx, has_rctx;
+	int32_t	n_sites, n_efn;
+	int32_t	efn_usestdbp, efn_stdbp;
+	int32_t	hit_stride;
+	int32_t	lmargin, rmargin;	// bases needed before szero / after the window
+	int8_t	searches[ RMD_MAX_ELEMS ];
+	rmd_elem_t	elems[ RMD_MAX_ELEMS ];
+	rmd_elem_t	lctx, rctx;
+	rmd_site_t	sites[ RMD_MAX_SITES ];
+	rmd_pairset_t	pairsets[ RMD_MAX_PS ];
+	rmd_regex_t	regexes[ RMD_MAX_RE ];
+	rma_efn_site_t	efn_sites[ RMD_MAX_EFN ];
+};
+
+// Build the device form; returns 0 or -1 with a message (descriptor outside
+// the device limits).  Implemented in rm_dev_program.cpp (host).
+int	rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t errlen );

@@ -11,7 +11,7 @@
 namespace rma {
 
 // What the driver needs from a scanner: scan n sequences (both strands when
-// the program says so) and return hit records sorted by (seq,comp,szero,order).
+// the program says so) and return hit records sorted by (seq,comp,szero,rank,order).
 // The product binary plugs the HIP scanner in here (rm_capi.cpp).
 struct ScanBackend {
 	void	*self;

@@ -1,0 +1,43 @@
+// rm_main.cpp -- the rnamotif executable: the reference's command line and
+// output (/root/reference/src/rnamot.c) with the scan on the GPU.  The scanner
+// is reached through the C ABI only; there is no CPU search path in this binary.
+#include "rm_cli.h"
+#include "rnamotif_amd.h"
+#include <cstdlib>
+
+namespace {
+
+struct HipBackend {
+	rma_scanner_t	*sc = nullptr;
+	rma_db_t	*db = nullptr;
+};
+
+int hip_scan( void *self, const char *const *seqs, const int32_t *slens, int n,
+	const int32_t **hits, int64_t *n_hits, char *err, size_t errlen )
+{
+	HipBackend	*hb = ( HipBackend * )self;
+	if( hb->db != nullptr ){
+		rma_db_destroy( hb->db );
+		hb->db = nullptr;
+	}
+	if( rma_db_create( hb->sc, seqs, slens, n, &hb->db, err, errlen ) )
+		return 1;
+	return rma_scan( hb->sc, hb->db, hits, n_hits, err, errlen );
+}
+
+rma::ScanBackend make_hip( const rma_program_t *prog, const rma_efndata_t *efn )
+{
+	HipBackend	*hb = new HipBackend;
+	char	err[ 1024 ] = "";
+	const char	*dv = getenv( "RNAMOTIF_DEVICE" );
+	if( rma_scanner_create( prog, efn, dv ? atoi( dv ) : 0, &hb->sc, err, sizeof( err ) ) )
+		rma::fail( "%s", err );
+	return rma::ScanBackend{ hb, hip_scan };
+}
+
+}	// namespace
+
+int main( int argc, char **argv )
+{
+	return rma::cli_main( argc, argv, make_hip );
+}

@@ -1,0 +1,974 @@
+// rm_scan_core.h -- the per-start-position motif search as an explicit state
+// machine: what find_motif()/find_1_motif()/find_ss()/find_wchlx()/find_pknot*()
+// /find_phlx()/find_triplex()/find_4plex*() do by recursion
+// (/root/reference/src/find_motif.c:245-973) is done here with one frame per
+// search level, so a GPU lane can run it without a call stack.
+//
+// Invariant used throughout: the reference only ever descends from search k to
+// search k+1 (s_forward, s_inner and "searchno + 1" all name it, compile.c:
+// 3128-3296), and each level's [zero,dollar] window has been written by an
+// earlier level before it is entered.  A level is a resumable generator of
+// alternatives; the driver loop below advances the deepest level, descends when
+// it yields, and pops when it is exhausted.
+//
+// The file is plain C++: the HIP kernel includes it with RMD_FN = __device__,
+// tests/hostsim compiles it for the CPU to debug the state machine without a
+// GPU.  Sequence access is through a byte array of base codes (0..4).
+#pragma once
+#include "rm_dev_program.h"
+
+#ifndef RMD_FN
+#define RMD_FN	static inline
+#endif
+
+#define RMD_UNDEF	(-1)
+
+struct rmd_frame_t {
+	int32_t	sd, sd_lo, o_sd;	// find_motif's sdollar loop: next value, last value, saved s_dollar
+	int32_t	ph;			// generator phase
+	int32_t	a, b, c, d, e, f;	// per-type loop variables
+	int32_t	i_minl;			// pknot: interior minimum for this (s5)
+	uint64_t	cand;		// helix lengths that match_wchlx accepted (bit hl)
+	uint64_t	mis;		// bit i: pair i of the helix is a mispair
+};
+
+struct rmd_lane_t {
+	int32_t	zero[ RMD_MAX_ELEMS ], dollar[ RMD_MAX_ELEMS ];	// SEARCH_T s_zero/s_dollar
+	int32_t	moff[ RMD_MAX_ELEMS ], mlen[ RMD_MAX_ELEMS ];	// s_matchoff/s_matchlen
+	int16_t	mpr[ RMD_MAX_ELEMS ], mm[ RMD_MAX_ELEMS ];	// s_n_mispairs/s_n_mismatches
+	rmd_frame_t	fr[ RMD_MAX_ELEMS ];
+	int32_t	l_off, l_len, r_off, r_len, l_mm, r_mm;
+	int32_t	slen;
+	int32_t	rank, order;
+};
+
+// sequence view: code of absolute position p is sq[ p - sq0 ]
+struct rmd_seq_t {
+	const uint8_t	*sq;
+	int32_t	sq0;
+};
+
+RMD_FN int rmd_code( const rmd_seq_t &s, int p ) { return s.sq[ p - s.sq0 ]; }
+
+RMD_FN int rmd_paired( const rmd_program_t *P, int ps, int b5, int b3 )		// RM_paired :1291
+{
+	return ( P->pairsets[ ps ].mat2 >> ( b5 * 5 + b3 ) ) & 1;
+}
+RMD_FN int rmd_triple( const rmd_program_t *P, int ps, int b1, int b2, int b3 )	// RM_triple :1304
+{
+	int	ix = ( b1 * 5 + b2 ) * 5 + b3;
+	return ( P->pairsets[ ps ].mat3[ ix >> 5 ] >> ( ix & 31 ) ) & 1;
+}
+RMD_FN int rmd_quad( const rmd_program_t *P, int ps, int b1, int b2, int b3, int b4 )	// RM_quad :1318
+{
+	int	ix = ( ( b1 * 5 + b2 ) * 5 + b3 ) * 5 + b4;
+	return ( P->pairsets[ ps ].mat4[ ix >> 5 ] >> ( ix & 31 ) ) & 1;
+}
+
+RMD_FN int rmd_popc64( uint64_t x )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+	return __popcll( x );
+#else
+	return __builtin_popcountll( x );
+#endif
+}
+RMD_FN int rmd_ctz64( uint64_t x )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+	return __ffsll( ( unsigned long long )x ) - 1;
+#else
+	return __builtin_ctzll( x );
+#endif
+}
+
+// ---------------------------------------------------------------- seq= constraints
+// step() semantics (regexp.c:389-664) as a set-of-positions automaton: after each
+// base, `act` holds the pattern positions that just consumed it.
+RMD_FN uint64_t rmd_re_close( const rmd_regex_t &re, uint64_t f )
+{
+	for( int k = 0; k < re.n_close; k++ )
+		f |= ( f & re.opt ) << 1;
+	return f;
+}
+
+RMD_FN int rmd_re_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len )
+{
+	uint64_t	act = 0, endbit = 1ull << re.n_states;
+	for( int pos = 0; ; pos++ ){
+		uint64_t	f = ( act << 1 ) | ( act & re.star );
+		if( pos == 0 || !re.anchored )
+			f |= 1;
+		f = rmd_re_close( re, f );
+		if( ( f & endbit ) && ( !re.dollar || pos == len ) )
+			return 1;
+		if( pos == len )
+			return 0;
+		act = f & re.accept[ rmd_code( sq, off + pos ) ];
+		if( act == 0 && re.anchored )
+			return 0;
+	}
+}
+
+// mm_step()/mm_advance() (mm_regexp.c:353-469): fixed length expressions only.
+// *n_mm is left as the last attempt left it.
+RMD_FN int rmd_re_mm_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len, int l_mm, int *n_mm )
+{
+	int	n = re.n_states;
+	for( int st = 0; ; st++ ){
+		int	cnt = 0, ok = 1;
+		for( int j = 0; j < n; j++ ){
+			if( st + j >= len ){
+				ok = 0;
+				break;
+			}
+			uint64_t	bit = 1ull << j;
+			if( re.dot & bit )
+				continue;
+			if( !( re.accept[ rmd_code( sq, off + st + j ) ] & bit ) ){
+				if( ++cnt > l_mm ){
+					ok = 0;
+					break;
+				}
+			}
+		}
+		if( ok && re.dollar && st + n != len )
+			ok = 0;
+		*n_mm = cnt;
+		if( ok )
+			return 1;
+		if( re.anchored || st >= len )
+			return 0;
+	}
+}
+
+// chk_seq(), find_motif.c:1810
+RMD_FN int rmd_chk_seq( const rmd_program_t *P, const rmd_elem_t &e, const rmd_seq_t &sq, int off, int len, int *n_mm )
+{
+	const rmd_regex_t	&re = P->regexes[ e.re ];
+	if( e.mismatch > 0 )
+		return rmd_re_mm_step( re, sq, off, len, e.mismatch, n_mm );
+	return rmd_re_step( re, sq, off, len );
+}
+
+// ---------------------------------------------------------------- helix matchers
+// match_wchlx(), find_motif.c:975.  Every candidate ends at s3, so the result
+// is the set of accepted lengths (bit hl of *cand) and the mispair positions.
+RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis )
+{
+	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
+	uint64_t	c = 0, m = 0;
+	int	hl, mpr, l_bpr, mm5 = L->mm[ d5 ], mm3 = L->mm[ d3 ];
+
+	if( stp.minlen == 0 ){
+		int	ok = 1;
+		if( stp.re >= 0 && !rmd_chk_seq( P, stp, sq, s5, 0, &mm5 ) )
+			ok = 0;
+		if( ok && ( stp3.re < 0 || rmd_chk_seq( P, stp3, sq, s3 + 1, 0, &mm3 ) ) )
+			c |= 1;
+	}
+	if( rmd_paired( P, stp.pairset, rmd_code( sq, s5 ), rmd_code( sq, s3 ) ) ){
+		hl = 1;
+		mpr = 0;
+		l_bpr = 1;
+	}else if( !( stp.ends & RMA_5PAIRED ) ){
+		hl = 1;
+		mpr = 1;
+		l_bpr = 0;
+		m |= 1;
+	}else{
+		L->mm[ d5 ] = int16_t( mm5 );
+		L->mm[ d3 ] = int16_t( mm3 );
+		*cand = c;
+		*mis = m;
+		return c != 0;
+	}
+	for( ; ; ){
+		if( hl >= stp.minlen ){
+			int	ok = 1;
+			if( !l_bpr && ( stp.ends & RMA_3PAIRED ) )
+				ok = 0;
+			else if( stp.pfrac && mpr > stp.pf_maxmpr[ hl ] )
+				ok = 0;
+			else if( stp.re >= 0 && !rmd_chk_seq( P, stp, sq, s5, hl, &mm5 ) )
+				ok = 0;
+			else if( stp3.re >= 0 && !rmd_chk_seq( P, stp3, sq, s3 - hl + 1, hl, &mm3 ) )
+				ok = 0;
+			if( ok )
+				c |= 1ull << hl;
+		}
+		if( !( s3 - hl + 1 >= s3lim ) )
+			break;
+		if( hl >= stp.maxlen )
+			break;
+		if( rmd_paired( P, stp.pairset, rmd_code( sq, s5 + hl ), rmd_code( sq, s3 - hl ) ) )
+			l_bpr = 1;
+		else{
+			mpr++;
+			if( mpr > stp.mplim )
+				break;
+			l_bpr = 0;
+			m |= 1ull << hl;
+		}
+		hl++;
+	}
+	L->mm[ d5 ] = int16_t( mm5 );
+	L->mm[ d3 ] = int16_t( mm3 );
+	*cand = c;
+	*mis = m;
+	return c != 0;
+}
+
+// match_phlx(), find_motif.c:1114
+RMD_FN int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+	int d5, int d3, int s5, int s3, int s5hi, int s5lo, int *hlen, int *n_mpr )
+{
+	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
+	int	b3 = rmd_code( sq, s3 );
+	for( int s = s5hi; s >= s5lo; s-- ){
+		int	hl, mpr, l_pr;
+		if( rmd_paired( P, stp.pairset, rmd_code( sq, s ), b3 ) ){
+			hl = 1;
+			mpr = 0;
+			l_pr = 1;
+		}else if( !( stp.ends & RMA_5PAIRED ) ){
+			hl = 1;
+			mpr = 1;
+			l_pr = 0;
+		}else
+			continue;
+		for( int s1 = s - 1; s1 >= s5; s1-- ){
+			if( rmd_paired( P, stp.pairset, rmd_code( sq, s1 ), rmd_code( sq, s3 - hl ) ) )
+				l_pr = 1;
+			else{
+				l_pr = 0;
+				if( ++mpr > stp.mplim )
+					return 0;
+			}
+			hl++;
+		}
+		if( !l_pr && ( stp.ends & RMA_3PAIRED ) )
+			return 0;
+		if( hl < stp.minlen || hl > stp.maxlen )
+			return 0;
+		if( stp.pfrac && mpr > stp.pf_maxmpr[ hl ] )
+			return 0;
+		int	mm;
+		if( stp.re >= 0 ){
+			mm = L->mm[ d5 ];
+			int	ok = rmd_chk_seq( P, stp, sq, s5, hl, &mm );
+			L->mm[ d5 ] = int16_t( mm );
+			if( !ok )
+				return 0;
+		}
+		if( stp3.re >= 0 ){
+			mm = L->mm[ d3 ];
+			int	ok = rmd_chk_seq( P, stp3, sq, s3 - hl + 1, hl, &mm );
+			L->mm[ d3 ] = int16_t( mm );
+			if( !ok )
+				return 0;
+		}
+		*hlen = hl;
+		*n_mpr = mpr;
+		return 1;
+	}
+	return 0;
+}
+
+// match_triplex(), find_motif.c:1183
+RMD_FN int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+	int d, int d1, int s1, int s2, int s3, int tlen, int *n_mpr )
+{
+	const rmd_elem_t	&stp = P->elems[ d ], &stp1 = P->elems[ d1 ];
+	int	mplim = stp.tq_mplim[ tlen ], mpr, l_pr;
+	if( rmd_triple( P, stp.pairset, rmd_code( sq, s1 ), rmd_code( sq, s2 ), rmd_code( sq, s3 - tlen + 1 ) ) ){
+		mpr = 0;
+		l_pr = 1;
+	}else if( !( stp.ends & RMA_5PAIRED ) ){
+		mpr = 1;
+		l_pr = 0;
+	}else
+		return 0;
+	for( int t = 1; t < tlen; t++ ){
+		if( !rmd_triple( P, stp.pairset, rmd_code( sq, s1 + t ), rmd_code( sq, s2 - t ), rmd_code( sq, s3 - tlen + 1 + t ) ) ){
+			l_pr = 0;
+			if( ++mpr > mplim )
+				return 0;
+		}else
+			l_pr = 1;
+	}
+	if( !l_pr && ( stp.ends & RMA_3PAIRED ) )
+		return 0;
+	if( stp1.re >= 0 ){
+		int	mm = L->mm[ d1 ];
+		int	ok = rmd_chk_seq( P, stp1, sq, s2 - tlen + 1, tlen, &mm );
+		L->mm[ d1 ] = int16_t( mm );
+		if( !ok )
+			return 0;
+	}
+	*n_mpr = mpr;
+	return 1;
+}
+
+// match_4plex(), find_motif.c:1234
+RMD_FN int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+	int d1, int d2, int s1, int s2, int s3, int s4, int qlen, int *n_mpr )
+{
+	const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
+	int	mplim = stp1.tq_mplim[ qlen ], mpr, l_pr;
+	if( rmd_quad( P, stp1.pairset, rmd_code( sq, s1 + qlen - 1 ), rmd_code( sq, s2 ), rmd_code( sq, s3 ), rmd_code( sq, s4 - qlen + 1 ) ) )
+		l_pr = 1;
+	else if( !( stp1.ends & RMA_5PAIRED ) )
+		l_pr = 0;
+	else
+		return 0;
+	mpr = 0;	// (sic) find_motif.c:1260 restarts the count after the first quad
+	for( int q = 1; q < qlen; q++ ){
+		if( !rmd_quad( P, stp1.pairset, rmd_code( sq, s1 + qlen - 1 - q ), rmd_code( sq, s2 + q ),
+			rmd_code( sq, s3 - q ), rmd_code( sq, s4 - qlen + 1 + q ) ) ){
+			l_pr = 0;
+			if( ++mpr > mplim )
+				return 0;
+		}else
+			l_pr = 1;
+	}
+	if( !l_pr && ( stp1.ends & RMA_3PAIRED ) )
+		return 0;
+	int	mm;
+	if( stp1.re >= 0 ){
+		mm = L->mm[ d1 ];
+		int	ok = rmd_chk_seq( P, stp1, sq, s2, qlen, &mm );
+		L->mm[ d1 ] = int16_t( mm );
+		if( !ok )
+			return 0;
+	}
+	if( stp2.re >= 0 ){
+		mm = L->mm[ d2 ];
+		int	ok = rmd_chk_seq( P, stp2, sq, s3 - qlen + 1, qlen, &mm );
+		L->mm[ d2 ] = int16_t( mm );
+		if( !ok )
+			return 0;
+	}
+	*n_mpr = mpr;
+	return 1;
+}
+
+// ---------------------------------------------------------------- terminal checks
+// fm_window[] lookup (find_motif.c:1333-1385 marks): type of the element that
+// covers position pos, RMA_T_SS when nothing does and undef_is_ss, else -1.
+RMD_FN int rmd_wtype( const rmd_program_t *P, const rmd_lane_t *L, int pos, int undef_is_ss )
+{
+	for( int d = 0; d < P->n_elems; d++ ){
+		if( L->mlen[ d ] > 0 && pos >= L->moff[ d ] && pos < L->moff[ d ] + L->mlen[ d ] )
+			return P->elems[ d ].type;
+	}
+	return undef_is_ss ? RMA_T_SS : -1;
+}
+
+RMD_FN int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_motif :1406
+{
+	for( int d = 0; d < P->n_elems; d++ ){
+		const rmd_elem_t	&stp = P->elems[ d ];
+		if( !stp.strict )
+			continue;
+		if( stp.type == RMA_T_H5 ){			// chk_wchlx :1441
+			int	d3 = stp.mates[ 0 ];
+			int	h5_5 = L->moff[ d ], h5_3 = h5_5 + L->mlen[ d ] - 1;
+			int	h3_5 = L->moff[ d3 ], h3_3 = h3_5 + L->mlen[ d3 ] - 1;
+			if( ( stp.strict & RMA_5STRICT ) && h5_5 > 0 && h3_3 < L->slen - 1 ){
+				if( rmd_wtype( P, L, h5_5 - 1, 1 ) == RMA_T_SS && rmd_wtype( P, L, h3_3 + 1, 1 ) == RMA_T_SS &&
+					rmd_paired( P, stp.pairset, rmd_code( sq, h5_5 - 1 ), rmd_code( sq, h3_3 + 1 ) ) )
+					return 0;
+			}
+			if( stp.strict & RMA_3STRICT ){
+				if( rmd_wtype( P, L, h5_3 + 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, h3_5 - 1, 0 ) == RMA_T_SS &&
+					rmd_paired( P, stp.pairset, rmd_code( sq, h5_3 + 1 ), rmd_code( sq, h3_5 - 1 ) ) )
+					return 0;
+			}
+		}else if( stp.type == RMA_T_T1 ){		// chk_triplex :1557
+			int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ];
+			int	t1_5 = L->moff[ d ], t1_3 = t1_5 + L->mlen[ d ] - 1;
+			int	t2_5 = L->moff[ d1 ], t2_3 = t2_5 + L->mlen[ d1 ] - 1;
+			int	t3_5 = L->moff[ d2 ], t3_3 = t3_5 + L->mlen[ d2 ] - 1;
+			if( ( stp.strict & RMA_5STRICT ) && t1_5 > 0 ){
+				if( rmd_wtype( P, L, t1_5 - 1, 1 ) == RMA_T_SS && rmd_wtype( P, L, t2_3 + 1, 0 ) == RMA_T_SS &&
+					rmd_wtype( P, L, t3_5 - 1, 0 ) == RMA_T_SS &&
+					rmd_triple( P, stp.pairset, rmd_code( sq, t1_5 - 1 ), rmd_code( sq, t2_3 + 1 ), rmd_code( sq, t3_5 - 1 ) ) )
+					return 0;
+			}
+			if( ( stp.strict & RMA_3STRICT ) && t3_3 < L->slen - 1 ){
+				if( rmd_wtype( P, L, t1_3 + 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, t2_5 - 1, 0 ) == RMA_T_SS &&
+					rmd_wtype( P, L, t3_3 + 1, 1 ) == RMA_T_SS &&
+					rmd_triple( P, stp.pairset, rmd_code( sq, t1_3 + 1 ), rmd_code( sq, t2_5 - 1 ), rmd_code( sq, t3_3 + 1 ) ) )
+					return 0;
+			}
+		}else if( stp.type == RMA_T_Q1 ){		// chk_4plex :1629
+			int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
+			int	q1_5 = L->moff[ d ], q1_3 = q1_5 + L->mlen[ d ] - 1;
+			int	q2_5 = L->moff[ d1 ], q2_3 = q2_5 + L->mlen[ d1 ] - 1;
+			int	q3_5 = L->moff[ d2 ], q3_3 = q3_5 + L->mlen[ d2 ] - 1;
+			int	q4_5 = L->moff[ d3 ], q4_3 = q4_5 + L->mlen[ d3 ] - 1;
+			if( ( stp.strict & RMA_5STRICT ) && q1_5 > 0 && q4_3 < L->slen - 1 ){
+				if( rmd_wtype( P, L, q1_5 - 1, 1 ) == RMA_T_SS && rmd_wtype( P, L, q2_3 + 1, 0 ) == RMA_T_SS &&
+					rmd_wtype( P, L, q3_5 - 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, q4_3 + 1, 1 ) == RMA_T_SS &&
+					rmd_quad( P, stp.pairset, rmd_code( sq, q1_5 - 1 ), rmd_code( sq, q2_3 + 1 ),
+						rmd_code( sq, q3_5 - 1 ), rmd_code( sq, q4_3 + 1 ) ) )
+					return 0;
+			}
+			if( stp.strict & RMA_3STRICT ){		// (sic) :1706 never looks at the q4 side
+				if( rmd_wtype( P, L, q1_3 + 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, q2_5 - 1, 0 ) == RMA_T_SS &&
+					rmd_wtype( P, L, q3_3 + 1, 0 ) == RMA_T_SS &&
+					rmd_quad( P, stp.pairset, rmd_code( sq, q1_3 + 1 ), rmd_code( sq, q2_5 - 1 ),
+						rmd_code( sq, q3_3 + 1 ), rmd_code( sq, q4_5 - 1 ) ) )
+					return 0;
+			}
+		}
+		// RMA_T_P5: chk_phlx :1500 returns TRUE on every path
+	}
+	return 1;
+}
+
+RMD_FN int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq )	// set_context :1720
+{
+	if( P->has_lctx ){
+		int	off = L->moff[ 0 ] - P->lctx.maxlen;
+		if( off < 0 )
+			off = 0;
+		L->l_off = off;
+		L->l_len = L->moff[ 0 ] - off;
+		if( L->l_len < P->lctx.minlen )
+			return 0;
+		if( P->lctx.re >= 0 && !rmd_chk_seq( P, P->lctx, sq, off, L->l_len, &L->l_mm ) )
+			return 0;
+	}
+	if( P->has_rctx ){
+		int	n = P->n_elems - 1;
+		L->r_off = L->moff[ n ] + L->mlen[ n ];
+		int	end = L->r_off + P->rctx.maxlen;
+		if( end > L->slen )
+			end = L->slen;
+		L->r_len = end - L->r_off;
+		if( L->r_len < P->rctx.minlen )
+			return 0;
+		if( P->rctx.re >= 0 ){
+			// (sic) :1749-1751 matches from the END of the context; the C string
+			// it builds stops at the end of the sequence
+			int	len = L->r_len;
+			if( len > L->slen - end )
+				len = L->slen - end;
+			if( !rmd_chk_seq( P, P->rctx, sq, end, len, &L->r_mm ) )
+				return 0;
+		}
+	}
+	return 1;
+}
+
+RMD_FN int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_sites :1758
+{
+	for( int s = 0; s < P->n_sites; s++ ){
+		const rmd_site_t	&si = P->sites[ s ];
+		int	b[ 4 ] = { 0, 0, 0, 0 };
+		for( int k = 0; k < si.n_pos; k++ ){
+			int	d = si.elem[ k ], pos;
+			if( si.l2r[ k ] ){
+				if( si.offset[ k ] > L->mlen[ d ] )
+					return 0;
+				pos = L->moff[ d ] + si.offset[ k ] - 1;
+			}else if( si.offset[ k ] >= L->mlen[ d ] )
+				return 0;
+			else
+				pos = L->moff[ d ] + L->mlen[ d ] - si.offset[ k ] - 1;
+			b[ k ] = rmd_code( sq, pos );
+		}
+		int	rv = 0;
+		if( si.n_pos == 2 )
+			rv = rmd_paired( P, si.pairset, b[ 0 ], b[ 1 ] );
+		else if( si.n_pos == 3 )
+			rv = rmd_triple( P, si.pairset, b[ 0 ], b[ 1 ], b[ 2 ] );
+		else if( si.n_pos == 4 )
+			rv = rmd_quad( P, si.pairset, b[ 0 ], b[ 1 ], b[ 2 ], b[ 3 ] );
+		if( !rv )
+			return 0;
+	}
+	return 1;
+}
+
+// ---------------------------------------------------------------- level generators
+RMD_FN int rmd_find_minlen( const rmd_program_t *P, const rmd_lane_t *L, int fd, int ld )	// :642
+{
+	int	v = 0;
+	for( int d = fd; d <= ld; d++ )
+		v += L->mlen[ d ] != RMD_UNDEF ? L->mlen[ d ] : P->elems[ d ].minlen;
+	return v;
+}
+RMD_FN int rmd_find_maxlen( const rmd_program_t *P, const rmd_lane_t *L, int fd, int ld )	// :655
+{
+	int	v = 0;
+	for( int d = fd; d <= ld; d++ )
+		v += L->mlen[ d ] != RMD_UNDEF ? L->mlen[ d ] : P->elems[ d ].maxlen;
+	return v;
+}
+
+RMD_FN void rmd_unmark( rmd_lane_t *L, int d ) { L->moff[ d ] = L->mlen[ d ] = RMD_UNDEF; }
+RMD_FN void rmd_mark( rmd_lane_t *L, int d, int off, int len ) { L->moff[ d ] = off; L->mlen[ d ] = len; }
+RMD_FN int rmd_imin( int a, int b ) { return a < b ? a : b; }
+
+RMD_FN int rmd_s3lim( int szero, int sdollar, int i_minl, int h_maxl )	// find_motif.c:426-429
+{
+	int	v = sdollar - szero + 1;
+	v = ( v - i_minl ) / 2;
+	v = rmd_imin( v, h_maxl );
+	return sdollar - v + 1;
+}
+
+// find_motif(), :245: prepare the loop over the level's end position
+RMD_FN void rmd_enter( const rmd_program_t *P, rmd_lane_t *L, int k )
+{
+	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
+	rmd_frame_t	&f = L->fr[ k ];
+	f.o_sd = L->dollar[ k ];
+	if( stp.loop ){
+		int	hi = L->dollar[ k ];
+		if( stp.maxglen != RMA_UNBOUNDED && L->zero[ k ] + stp.maxglen - 1 < hi )
+			hi = L->zero[ k ] + stp.maxglen - 1;
+		f.sd = hi;
+		f.sd_lo = L->zero[ k ] + stp.minglen - 1;
+	}else
+		f.sd = f.sd_lo = L->dollar[ k ];
+	f.ph = 0;
+}
+
+// phlx/triplex end bounds, find_motif.c:730-739, :801-810
+RMD_FN void rmd_phlx_bounds( int szero, int slen, int h_minl, int h_maxl, int i_minl, int i_maxsum, int *s5hi, int *s5lo )
+{
+	int	hi = rmd_imin( ( slen - i_minl ) / 2, h_maxl );
+	*s5hi = szero + hi - 1;
+	int	ilen = rmd_imin( slen - 2 * h_minl, i_maxsum );
+	int	lo = slen - ilen;
+	if( lo & 1 )
+		lo++;
+	lo = rmd_imin( lo / 2, h_maxl );
+	*s5lo = szero + lo - 1;
+}
+
+// upd_pksearches(), :667
+RMD_FN void rmd_upd_pksearches( const rmd_program_t *P, rmd_lane_t *L, int d, int h5, int h3, int hlen )
+{
+	const rmd_elem_t	&stp = P->elems[ d ];
+	int	i;
+	if( stp.scope > 0 ){
+		i = P->elems[ stp.scopes[ stp.scope - 1 ] ].inner_s;
+		if( i >= 0 )
+			L->dollar[ i ] = h5 - 1;
+	}
+	if( stp.inner_s >= 0 )
+		L->zero[ stp.inner_s ] = h5 + hlen;
+	const rmd_elem_t	&stp3 = P->elems[ stp.mates[ 0 ] ];
+	i = P->elems[ stp3.scopes[ stp3.scope - 1 ] ].inner_s;
+	if( i >= 0 )
+		L->dollar[ i ] = h3 - hlen;
+	if( stp3.scope < stp3.n_scopes - 1 && stp3.inner_s >= 0 )
+		L->zero[ stp3.inner_s ] = h3 + 1;
+}
+
+// Advance level k to its next alternative.  Returns 1 with the alternative
+// applied (elements marked, later windows set), 0 when the level is exhausted.
+RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
+{
+	const int	d = P->searches[ k ];
+	const rmd_elem_t	&stp = P->elems[ d ];
+	rmd_frame_t	&f = L->fr[ k ];
+
+	for( ; ; ){
+		if( f.ph == 0 ){
+			// next end position of find_motif's loop
+			if( f.sd < f.sd_lo ){
+				L->dollar[ k ] = f.o_sd;
+				return 0;
+			}
+			if( stp.loop ){
+				if( k == 0 ){
+					L->rank++;
+					L->order = 0;
+				}
+				L->dollar[ k ] = f.sd;
+				if( stp.next_s >= 0 ){
+					L->zero[ stp.next_s ] = f.sd + 1;
+					L->dollar[ stp.next_s ] = f.o_sd;
+				}
+			}
+			f.sd--;
+			const int	szero = L->zero[ k ], sdollar = L->dollar[ k ], slen = sdollar - szero + 1;
+			switch( stp.type ){
+			case RMA_T_SS : {			// find_ss :332
+				L->mm[ d ] = 0;
+				L->mpr[ d ] = 0;
+				if( slen < stp.minlen || slen > stp.maxlen )
+					continue;
+				if( stp.re >= 0 ){
+					int	mm = 0;
+					int	ok = rmd_chk_seq( P, stp, sq, szero, slen, &mm );
+					L->mm[ d ] = int16_t( mm );
+					if( !ok )
+						continue;
+				}
+				rmd_mark( L, d, szero, slen );
+				f.ph = 1;
+				return 1;
+			}
+			case RMA_T_H5 :
+				if( stp.proper ){		// find_wchlx :400
+					int	d3 = stp.mates[ 0 ];
+					L->mm[ d ] = L->mpr[ d ] = 0;
+					L->mm[ d3 ] = L->mpr[ d3 ] = 0;
+					int	s3lim = rmd_s3lim( szero, sdollar, stp.minilen, stp.maxlen );
+					if( !rmd_match_wchlx( P, L, sq, d, d3, szero, sdollar, s3lim, &f.cand, &f.mis ) )
+						continue;
+					f.ph = 1;
+				}else{				// find_pknot :465, find_pknot5 :495
+					if( stp.scope == 0 ){
+						for( int s = 1; s < stp.n_scopes; s++ ){
+							int	d1 = stp.scopes[ s ];
+							if( P->elems[ d1 ].type == RMA_T_H5 ){
+								int	s1 = P->elems[ d1 ].searchno;
+								rmd_unmark( L, d1 );
+								L->zero[ s1 ] = szero;
+								L->dollar[ s1 ] = sdollar;
+							}
+						}
+					}
+					int	d0 = stp.scopes[ 0 ], dn = stp.scopes[ stp.n_scopes - 1 ];
+					int	p_minl = rmd_find_minlen( P, L, d0, d - 1 ), p_maxl = rmd_find_maxlen( P, L, d0, d - 1 );
+					int	r_minl = rmd_find_minlen( P, L, d, dn ), r_maxl = rmd_find_maxlen( P, L, d, dn );
+					if( p_maxl + r_maxl < slen )
+						continue;
+					f.a = szero + p_minl;					// s5
+					f.b = szero + rmd_imin( p_maxl, slen - r_minl );	// l_s5
+					f.ph = 1;
+				}
+				break;
+			case RMA_T_P5 : {			// find_phlx :703
+				int	d3 = stp.mates[ 0 ];
+				L->mm[ d ] = L->mpr[ d ] = 0;
+				L->mm[ d3 ] = L->mpr[ d3 ] = 0;
+				int	s5hi, s5lo, hlen, n_mpr;
+				rmd_phlx_bounds( szero, slen, stp.minlen, stp.maxlen, stp.minilen, stp.maxilen, &s5hi, &s5lo );
+				if( !rmd_match_phlx( P, L, sq, d, d3, szero, sdollar, s5hi, s5lo, &hlen, &n_mpr ) )
+					continue;
+				if( sdollar - szero - 2 * hlen + 1 > stp.maxilen )
+					continue;
+				L->mpr[ d ] = L->mpr[ d3 ] = int16_t( n_mpr );
+				rmd_mark( L, d, szero, hlen );
+				rmd_mark( L, d3, sdollar - hlen + 1, hlen );
+				L->zero[ stp.inner_s ] = szero + hlen;
+				L->dollar[ stp.inner_s ] = sdollar - hlen;
+				f.ph = 1;
+				return 1;
+			}
+			case RMA_T_T1 : {			// find_triplex :763
+				int	d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
+				const rmd_elem_t	&stp1 = P->elems[ d1 ];
+				L->mm[ d ] = L->mpr[ d ] = 0;
+				L->mm[ d1 ] = L->mpr[ d1 ] = 0;
+				L->mm[ d2 ] = L->mpr[ d2 ] = 0;
+				int	s5hi, s5lo, hlen, n_mpr;
+				rmd_phlx_bounds( szero, slen, stp.minlen, stp.maxlen, stp.minilen + stp1.minilen,
+					stp.maxilen + stp.minlen + stp1.maxilen, &s5hi, &s5lo );
+				if( !rmd_match_phlx( P, L, sq, d, d2, szero, sdollar, s5hi, s5lo, &hlen, &n_mpr ) )
+					continue;
+				if( sdollar - szero - 2 * hlen + 1 > stp.maxilen + stp1.maxilen + hlen )
+					continue;
+				rmd_mark( L, d, szero, hlen );
+				rmd_mark( L, d2, sdollar - hlen + 1, hlen );
+				f.c = hlen;
+				f.a = sdollar - stp1.minilen - hlen;			// s
+				f.b = szero + 2 * hlen + stp.minilen - 1;		// last s
+				f.ph = 1;
+				break;
+			}
+			case RMA_T_Q1 : {			// find_4plex :851
+				int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
+				L->mm[ d ] = L->mpr[ d ] = 0;
+				L->mm[ d1 ] = L->mpr[ d1 ] = 0;
+				L->mm[ d2 ] = L->mpr[ d2 ] = 0;
+				L->mm[ d3 ] = L->mpr[ d3 ] = 0;
+				int	i_minl = stp.minilen + P->elems[ d1 ].minilen + P->elems[ d2 ].minilen + 2 * stp.minlen;
+				int	s3lim = rmd_s3lim( szero, sdollar, i_minl, stp.maxlen );
+				if( !rmd_match_wchlx( P, L, sq, d, d3, szero, sdollar, s3lim, &f.cand, &f.mis ) )
+					continue;
+				f.ph = 1;
+				break;
+			}
+			default :
+				continue;
+			}
+			continue;
+		}
+
+		// ph != 0: produce the next alternative at the current end position
+		const int	szero = L->zero[ k ], sdollar = L->dollar[ k ];
+		switch( stp.type ){
+		case RMA_T_SS :
+			rmd_unmark( L, d );
+			f.ph = 0;
+			continue;
+		case RMA_T_H5 :
+			if( stp.proper ){
+				int	d3 = stp.mates[ 0 ];
+				rmd_unmark( L, d );
+				rmd_unmark( L, d3 );
+				if( f.cand == 0 ){
+					f.ph = 0;
+					continue;
+				}
+				int	hl = rmd_ctz64( f.cand );
+				f.cand &= f.cand - 1;
+				if( sdollar - szero - 2 * hl + 1 > stp.maxilen )
+					continue;
+				int	mpr = rmd_popc64( f.mis & ( ( 1ull << hl ) - 1 ) );
+				L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
+				rmd_mark( L, d, szero, hl );
+				rmd_mark( L, d3, sdollar - hl + 1, hl );
+				L->zero[ stp.inner_s ] = szero + hl;
+				L->dollar[ stp.inner_s ] = sdollar - hl;
+				return 1;
+			}else{
+				int	d3 = stp.mates[ 0 ];
+				int	dn = stp.scopes[ stp.n_scopes - 1 ];
+				if( f.ph == 3 ){		// next helix length at (s5,s3), find_pknot3 :607
+					rmd_unmark( L, d );
+					rmd_unmark( L, d3 );
+					const int	s5 = f.e, s3 = f.f;
+					if( f.cand == 0 ){
+						f.ph = 2;
+						continue;
+					}
+					int	hl = rmd_ctz64( f.cand );
+					f.cand &= f.cand - 1;
+					if( ( s3 - s5 + 1 ) - 2 * hl < f.i_minl ){
+						f.ph = 2;	// break: longer helices only get worse
+						continue;
+					}
+					if( d == stp.scopes[ 1 ] ){	// hlx == 2, :571-627
+						int	d3_h1 = P->elems[ stp.scopes[ 0 ] ].mates[ 0 ];
+						int	iL_last = L->moff[ d3_h1 ] - 1, iR_last = L->moff[ d3_h1 ] + L->mlen[ d3_h1 ];
+						int	iL_minl = 0, iL_maxl = 0, iR_minl = 0, iR_maxl = 0;
+						if( d + 1 <= d3_h1 - 1 ){
+							iL_minl = rmd_find_minlen( P, L, d + 1, d3_h1 - 1 );
+							iL_maxl = rmd_find_maxlen( P, L, d + 1, d3_h1 - 1 );
+						}
+						if( d3_h1 + 1 <= d3 - 1 ){
+							iR_minl = rmd_find_minlen( P, L, d3_h1 + 1, d3 - 1 );
+							iR_maxl = rmd_find_maxlen( P, L, d3_h1 + 1, d3 - 1 );
+						}
+						int	il = iL_last - ( s5 + hl - 1 ), ir = ( s3 - hl + 1 ) - iR_last;
+						if( il < iL_minl || il > iL_maxl || ir < iR_minl || ir > iR_maxl )
+							continue;
+					}
+					int	mpr = rmd_popc64( f.mis & ( ( 1ull << hl ) - 1 ) );
+					L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
+					rmd_mark( L, d, s5, hl );
+					rmd_mark( L, d3, s3 - hl + 1, hl );
+					rmd_upd_pksearches( P, L, d, s5, s3, hl );
+					return 1;
+				}
+				if( f.ph == 2 ){		// next 3' end, find_pknot3 :600
+					if( f.c < f.d ){
+						f.ph = 1;
+						continue;
+					}
+					const int	s5 = f.e, s3 = f.c--;
+					f.f = s3;
+					int	s3lim = rmd_s3lim( s5, s3, f.i_minl, stp.maxlen );
+					if( rmd_match_wchlx( P, L, sq, d, d3, s5, s3, s3lim, &f.cand, &f.mis ) )
+						f.ph = 3;
+					continue;
+				}
+				// ph == 1: next 5' start, find_pknot5 :523 / find_pknot3 :548-568
+				if( f.a > f.b ){
+					f.ph = 0;
+					continue;
+				}
+				const int	s5 = f.a++;
+				int	slen3 = sdollar - s5 + 1;
+				int	i_minl = rmd_find_minlen( P, L, d + 1, d3 - 1 );
+				int	g_minl = 2 * stp.minlen + i_minl;
+				int	s_minl = rmd_find_minlen( P, L, d3 + 1, dn ), s_maxl = rmd_find_maxlen( P, L, d3 + 1, dn );
+				if( g_minl + s_minl > slen3 )
+					continue;
+				f.e = s5;
+				f.i_minl = i_minl;
+				f.c = sdollar - s_minl;						// f_s3
+				f.d = sdollar - rmd_imin( slen3 - g_minl, s_maxl );		// l_s3
+				f.ph = 2;
+				continue;
+			}
+		case RMA_T_P5 :
+			rmd_unmark( L, d );
+			rmd_unmark( L, stp.mates[ 0 ] );
+			f.ph = 0;
+			continue;
+		case RMA_T_T1 : {
+			int	d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
+			const rmd_elem_t	&stp1 = P->elems[ d1 ];
+			const int	hlen = f.c;
+			rmd_unmark( L, d1 );
+			int	found = 0;
+			while( f.a >= f.b ){
+				int	s = f.a--;
+				int	n_mpr;
+				if( !rmd_match_triplex( P, L, sq, d, d1, szero, s, sdollar, hlen, &n_mpr ) )
+					continue;
+				if( s - 2 * hlen - szero + 1 > stp.maxilen )
+					continue;
+				if( sdollar - hlen - s > stp1.maxilen )
+					continue;
+				L->mpr[ d ] = L->mpr[ d1 ] = L->mpr[ d2 ] = int16_t( n_mpr );
+				rmd_mark( L, d1, s - hlen + 1, hlen );
+				L->zero[ stp.inner_s ] = szero + hlen;
+				L->dollar[ stp.inner_s ] = s - hlen;
+				L->zero[ stp1.inner_s ] = s + 1;
+				L->dollar[ stp1.inner_s ] = sdollar - hlen;
+				found = 1;
+				break;
+			}
+			if( found )
+				return 1;
+			rmd_unmark( L, d );
+			rmd_unmark( L, d2 );
+			f.ph = 0;
+			continue;
+		}
+		case RMA_T_Q1 : {
+			int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
+			const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
+			if( f.ph == 1 ){		// next outer helix length, find_4plex :893
+				rmd_unmark( L, d );
+				rmd_unmark( L, d3 );
+				if( f.cand == 0 ){
+					f.ph = 0;
+					continue;
+				}
+				int	hl = rmd_ctz64( f.cand );
+				f.cand &= f.cand - 1;
+				rmd_mark( L, d, szero, hl );
+				rmd_mark( L, d3, sdollar - hl + 1, hl );
+				f.c = hl;
+				f.a = szero + hl + stp.minilen;					// s1
+				f.b = sdollar - 3 * hl - stp2.minilen - stp1.minilen;		// s1lim
+				f.d = sdollar - hl - stp2.minilen;				// s2
+				f.ph = 2;
+				continue;
+			}
+			// ph == 2: find_4plex_inner :902, s1 upwards, s2 downwards
+			const int	hl = f.c, s3 = sdollar;
+			rmd_unmark( L, d1 );
+			rmd_unmark( L, d2 );
+			int	found = 0;
+			while( f.a <= f.b ){
+				int	s1 = f.a;
+				int	s2lim = s1 + 2 * hl + stp1.minilen;
+				if( f.d < s2lim ){
+					f.a++;
+					f.d = s3 - hl - stp2.minilen;
+					continue;
+				}
+				int	s2 = f.d--;
+				int	n_mpr;
+				if( !rmd_match_4plex( P, L, sq, d1, d2, szero, s1, s2, s3, hl, &n_mpr ) )
+					continue;
+				if( s1 - szero - hl + 1 > stp.maxilen )
+					continue;
+				if( s2 - s1 - 2 * hl + 1 > stp1.maxilen )
+					continue;
+				if( s3 - s2 - hl + 1 > stp2.maxilen )
+					continue;
+				L->mpr[ d ] = L->mpr[ d1 ] = L->mpr[ d2 ] = L->mpr[ d3 ] = int16_t( n_mpr );
+				rmd_mark( L, d1, s1, hl );
+				rmd_mark( L, d2, s2 - hl + 1, hl );
+				L->zero[ stp.inner_s ] = szero + hl;
+				L->dollar[ stp.inner_s ] = s1 - 1;
+				L->zero[ stp1.inner_s ] = s1 + hl;
+				L->dollar[ stp1.inner_s ] = s2 - hl;
+				L->zero[ stp2.inner_s ] = s2 + 1;
+				L->dollar[ stp2.inner_s ] = s3 - hl;
+				found = 1;
+				break;
+			}
+			if( found )
+				return 1;
+			f.ph = 1;
+			continue;
+		}
+		default :
+			f.ph = 0;
+			continue;
+		}
+	}
+}
+
+// Write one candidate (find_ss :373-392 up to the RM_score() call).
+RMD_FN void rmd_fill_hit( const rmd_program_t *P, const rmd_lane_t *L, int seq, int comp, int szero, int32_t *w )
+{
+	w[ 0 ] = seq;
+	w[ 1 ] = comp;
+	w[ 2 ] = szero;
+	w[ 3 ] = L->rank;
+	w[ 4 ] = L->order;
+	for( int d = 0; d < P->n_elems; d++ ){
+		w[ RMA_HIT_HDR + 4 * d + 0 ] = L->moff[ d ];
+		w[ RMA_HIT_HDR + 4 * d + 1 ] = L->mlen[ d ];
+		w[ RMA_HIT_HDR + 4 * d + 2 ] = L->mpr[ d ];
+		w[ RMA_HIT_HDR + 4 * d + 3 ] = L->mm[ d ];
+	}
+	int	k = RMA_HIT_HDR + 4 * P->n_elems;
+	w[ k + 0 ] = P->has_lctx ? L->l_off : 0;
+	w[ k + 1 ] = P->has_lctx ? L->l_len : 0;
+	w[ k + 2 ] = P->has_rctx ? L->r_off : 0;
+	w[ k + 3 ] = P->has_rctx ? L->r_len : 0;
+	for( int e = 0; e < P->n_efn; e++ )
+		w[ k + 4 + e ] = RMA_EFN_INFINITY;	// filled by the efn pass
+}
+
+// The search for one start position (one iteration of RM_find_motif's loops,
+// find_motif.c:184-205).  Sink::put( lane ) stores the candidate.
+template< class Sink >
+RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+	int szero, int slen, Sink &sink )
+{
+	for( int i = 0; i < P->n_elems; i++ ){
+		L->moff[ i ] = L->mlen[ i ] = RMD_UNDEF;
+		L->mpr[ i ] = L->mm[ i ] = RMD_UNDEF;
+	}
+	L->l_mm = L->r_mm = RMD_UNDEF;
+	L->l_off = L->l_len = L->r_off = L->r_len = 0;
+	L->slen = slen;
+	L->rank = -1;
+	L->order = 0;
+	L->zero[ 0 ] = szero;
+	L->dollar[ 0 ] = rmd_imin( szero + P->w_winsize - 1, slen - 1 );
+	const int	last = P->n_searches - 1;
+	int	k = 0;
+	rmd_enter( P, L, 0 );
+	while( k >= 0 ){
+		if( !rmd_next( P, L, sq, k ) ){
+			k--;
+			continue;
+		}
+		if( k < last ){
+			k++;
+			rmd_enter( P, L, k );
+			continue;
+		}
+		// end of the search list: find_ss :362-393
+		if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
+			continue;
+		if( !rmd_set_context( P, L, sq ) )
+			continue;
+		if( !rmd_chk_sites( P, L, sq ) )
+			continue;
+		sink.put( P, L, szero );
+		L->order++;
+	}
+}

@@ -1,0 +1,492 @@
+// rm_scan_hip.hip -- the scan path on MI355X (gfx950): search kernel, efn
+// kernel, and the scanner / database halves of the C ABI (include/rnamotif_amd.h).
+//
+// What runs here is the reference's RM_find_motif() for every start position of
+// every sequence and strand (/root/reference/src/find_motif.c:164-207), one
+// lane per start position, and RM_efn() (/root/reference/src/efn.c:1162) for
+// every candidate and efn() call site, one lane per candidate.
+//
+// Data layout in HBM (details in DESIGN.md):
+//   codes  2 bits/base, 16 bases per uint32; amask 1 bit/base, 32 per uint32;
+//          every sequence starts on a 32-base boundary
+//   hits   fixed-stride int32 records, appended through one atomic counter
+// A workgroup owns a tile of T consecutive start positions of one strand; it
+// decodes the T + w - 1 (+ context margins) bases the tile can touch into LDS
+// as one byte per base (codes 0..4, reverse strand complemented on the fly) and
+// keeps the motif program in LDS as well.  Tiles are handed out through an
+// atomic ticket so that long searches do not stall a fixed schedule.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#define RMD_FN		static __device__ inline
+#define RMD_FN_MEMBER	__device__ inline
+#include "rm_scan_core.h"
+#include "rm_efn_core.h"
+#include "rm_fasta.h"
+#include "rnamotif_amd.h"
+
+// ---------------------------------------------------------------- device views
+struct DbView {
+	const uint32_t	*codes, *amask;
+	const int64_t	*base_off;	// [n_seq]   first base of sequence s (multiple of 32)
+	const int32_t	*slen;		// [n_seq]
+	const int64_t	*tile_start;	// [n_seq+1] prefix sum of tiles over sequences
+	int32_t	n_seq, strands, tile_t;
+	int64_t	n_tiles;
+};
+
+struct HitBuf {
+	int32_t	*hits;
+	unsigned long long	*count;		// candidates found (may exceed cap)
+	unsigned long long	*ticket;	// next tile
+	int64_t	cap;
+};
+
+__device__ inline int db_code( const DbView &db, int64_t base )	// forward strand code of absolute base
+{
+	uint32_t	am = db.amask[ base >> 5 ];
+	if( ( am >> ( base & 31 ) ) & 1 )
+		return RMA_BC_N;
+	return ( db.codes[ base >> 4 ] >> ( 2 * ( base & 15 ) ) ) & 3;
+}
+
+// code at strand position p of sequence (off,slen), strand comp (mk_rcmp, rnamot.c:193)
+__device__ inline int db_strand_code( const DbView &db, int64_t off, int slen, int comp, int p )
+{
+	int	c = db_code( db, off + ( comp ? slen - 1 - p : p ) );
+	return ( comp && c < 4 ) ? 3 - c : c;
+}
+
+struct DevSink {
+	HitBuf	hb;
+	int	seq, comp, stride;
+	__device__ inline void put( const rmd_program_t *P, const rmd_lane_t *L, int szero )
+	{
+		unsigned long long	slot = atomicAdd( hb.count, 1ull );
+		if( slot < ( unsigned long long )hb.cap )
+			rmd_fill_hit( P, L, seq, comp, szero, hb.hits + slot * stride );
+	}
+};
+
+#define PROG_LDS_BYTES	( ( sizeof( rmd_program_t ) + 15 ) & ~size_t( 15 ) )
+
+// ---------------------------------------------------------------- search kernel
+template< int BLOCK >
+__global__ void __launch_bounds__( BLOCK )
+rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes )
+{
+	extern __shared__ __align__( 16 ) unsigned char	smem[];
+	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
+	uint8_t	*tile = smem + PROG_LDS_BYTES;
+	__shared__ long long	s_tile;
+	__shared__ int	s_seq;
+	const int	tid = threadIdx.x;
+
+	for( unsigned i = tid; i < sizeof( rmd_program_t ) / 4; i += BLOCK )
+		reinterpret_cast<uint32_t *>( P )[ i ] = reinterpret_cast<const uint32_t *>( gP )[ i ];
+	__syncthreads();
+
+	const int	T = db.tile_t;
+	const int	w = P->w_winsize, lm = P->lmargin, rm = P->rmargin;
+	rmd_lane_t	lane;
+
+	for( ; ; ){
+		if( tid == 0 ){
+			long long	t = ( long long )atomicAdd( hb.ticket, 1ull );
+			int	s = 0;
+			if( t < db.n_tiles ){
+				// last sequence whose first tile is <= t
+				int	lo = 0, hi = db.n_seq - 1;
+				while( lo < hi ){
+					int	mid = ( lo + hi + 1 ) >> 1;
+					if( db.tile_start[ mid ] <= t )
+						lo = mid;
+					else
+						hi = mid - 1;
+				}
+				s = lo;
+			}
+			s_tile = t;
+			s_seq = s;
+		}
+		__syncthreads();
+		const long long	t = s_tile;
+		if( t >= db.n_tiles )
+			break;
+		const int	seq = s_seq;
+		const int	slen = db.slen[ seq ];
+		const int64_t	off = db.base_off[ seq ];
+		const int	local = int( t - db.tile_start[ seq ] );
+		const int	per_strand = int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands );
+		const int	comp = local / per_strand;
+		const int	z0 = ( local % per_strand ) * T;
+
+		// decode the bases this tile can touch: [ z0 - lm, z0 + T + w - 1 + rm )
+		const int	p_lo = z0 - lm;
+		int	p_from = p_lo < 0 ? 0 : p_lo;
+		int	p_to = z0 + T + w - 1 + rm;
+		if( p_to > slen )
+			p_to = slen;
+		for( int p = p_from + tid; p < p_to; p += BLOCK )
+			tile[ p - p_lo ] = uint8_t( db_strand_code( db, off, slen, comp, p ) );
+		__syncthreads();
+
+		const int	szero = z0 + tid;
+		if( tid < T && szero <= slen - P->dminlen ){
+			rmd_seq_t	sq{ tile, p_lo };
+			DevSink	sink{ hb, seq, comp, P->hit_stride };
+			rmd_search_position( P, &lane, sq, szero, slen, sink );
+		}
+		__syncthreads();
+	}
+	( void )tile_bytes;
+}
+
+// ---------------------------------------------------------------- efn kernel
+struct DevSeq {
+	DbView	db;
+	int64_t	off;
+	int	slen, comp;
+	__device__ inline int code( int p ) const { return db_strand_code( db, off, slen, comp, p ); }
+};
+
+template< int BLOCK >
+__global__ void __launch_bounds__( BLOCK )
+rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
+	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc )
+{
+	__shared__ int16_t	t16[ RME_N16 ];
+	for( int i = threadIdx.x; i < RME_N16; i += BLOCK )
+		t16[ i ] = g16[ i ];
+	__syncthreads();
+	long long	h = ( long long )blockIdx.x * BLOCK + threadIdx.x;
+	if( h >= n_hits )
+		return;
+	rme_tables_t	T{ t16, tlkey, loginc };
+	int32_t	*w = hits + h * gP->hit_stride;
+	DevSeq	sq{ db, db.base_off[ w[ 0 ] ], db.slen[ w[ 0 ] ], w[ 1 ] };
+	const int	efn_off = RMA_HIT_HDR + 4 * gP->n_elems + 4;
+	for( int k = 0; k < gP->n_efn; k++ )
+		w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k );
+}
+
+// ---------------------------------------------------------------- host side
+#define HIPCHK( call )	do{ hipError_t e_ = ( call ); if( e_ != hipSuccess ){ \
+		snprintf( err, errlen, "%s: %s", #call, hipGetErrorString( e_ ) ); return 1; } }while( 0 )
+
+struct rma_scanner {
+	rma_program_t	prog;
+	rmd_program_t	dprog;
+	int	device = 0;
+	hipStream_t	stream = nullptr;
+	hipEvent_t	ev[ 4 ] = { nullptr, nullptr, nullptr, nullptr };
+	rmd_program_t	*d_prog = nullptr;
+	int16_t	*d_t16 = nullptr;
+	int32_t	*d_tlkey = nullptr, *d_loginc = nullptr;
+	bool	have_efn = false;
+	int32_t	*d_hits = nullptr;
+	int64_t	hit_cap = 0;
+	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
+	std::vector<int32_t>	h_raw, h_sorted;
+	int	tile_t = 256;
+	int	grid_blocks = 0;
+};
+
+struct rma_db {
+	rma_scanner	*sc;
+	uint32_t	*d_codes = nullptr, *d_amask = nullptr;
+	int64_t	*d_base_off = nullptr, *d_tile_start = nullptr;
+	int32_t	*d_slen = nullptr;
+	int32_t	n_seq = 0;
+	int64_t	n_tiles = 0, total_bases = 0;
+	int	strands = 2;
+};
+
+static void build_tables16( const rma_efndata_t *ed, std::vector<int16_t> &t16, std::vector<int32_t> &tlkey )
+{
+	t16.assign( RME_N16, 0 );
+	tlkey.assign( 100, -1 );
+	auto put = [&]( int off, const int32_t *src, int n ){
+		for( int i = 0; i < n; i++ ){
+			int	v = src[ i ];
+			t16[ off + i ] = int16_t( v > 32767 ? 32767 : v < -32768 ? -32768 : v );
+		}
+	};
+	put( RME_INTER, ed->inter, 31 );
+	put( RME_BULGE, ed->bulge, 31 );
+	put( RME_HAIRPIN, ed->hairpin, 31 );
+	put( RME_DANGLE, &ed->dangle[ 0 ][ 0 ][ 0 ][ 0 ], 250 );
+	put( RME_POPPEN, ed->poppen, 5 );
+	put( RME_EPARAM, ed->eparam, 16 );
+	int32_t	misc[ 9 ] = { ed->maxpen, ed->auend, ed->gubonus, ed->cslope, ed->cint, ed->c3, ed->gail,
+		ed->ntriloops, ed->ntloops };
+	put( RME_MISC, misc, 9 );
+	for( int k = 0; k < 50; k++ ){
+		// a key that does not fit 15 bits can never equal a computed key's low part
+		// by accident: store -1 (no computed key is negative)
+		int	key = k < ed->ntriloops ? ed->triloops[ k ][ 0 ] : -1;
+		t16[ RME_TRIKEY + k ] = int16_t( key >= 0 && key <= 32767 ? key : -1 );
+		t16[ RME_TRIVAL + k ] = int16_t( k < ed->ntriloops ? ed->triloops[ k ][ 1 ] : 0 );
+	}
+	for( int k = 0; k < 100; k++ ){
+		tlkey[ k ] = k < ed->ntloops ? ed->tloops[ k ][ 0 ] : -1;
+		t16[ RME_TLVAL + k ] = int16_t( k < ed->ntloops ? ed->tloops[ k ][ 1 ] : 0 );
+	}
+	put( RME_STACK, &ed->stack[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
+	put( RME_TSTKH, &ed->tstkh[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
+	put( RME_TSTKI, &ed->tstki[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
+	put( RME_SINT2, &ed->sint2[ 0 ][ 0 ][ 0 ][ 0 ], 900 );
+	put( RME_ASINT, &ed->asint1x2[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 4500 );
+	put( RME_SINT4, &ed->sint4[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 22500 );
+}
+
+extern "C" int rma_device_count( void )
+{
+	int	n = 0;
+	if( hipGetDeviceCount( &n ) != hipSuccess )
+		return 0;
+	return n;
+}
+
+extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_t *efn, int device,
+	rma_scanner_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	int	ndev = 0;
+	if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 ){
+		snprintf( err, errlen, "no HIP device available: the rnamotif scan path runs on the GPU only" );
+		return 1;
+	}
+	if( device < 0 || device >= ndev ){
+		snprintf( err, errlen, "device %d out of range (0..%d)", device, ndev - 1 );
+		return 1;
+	}
+	rma_scanner	*sc = new rma_scanner;
+	sc->prog = *prog;
+	if( rmd_build( prog, &sc->dprog, err, errlen ) ){
+		delete sc;
+		return 1;
+	}
+	if( prog->n_efn_sites > 0 && efn == nullptr ){
+		snprintf( err, errlen, "the program has efn() call sites but no energy tables were given" );
+		delete sc;
+		return 1;
+	}
+	sc->device = device;
+	HIPCHK( hipSetDevice( device ) );
+	HIPCHK( hipStreamCreate( &sc->stream ) );
+	for( int i = 0; i < 4; i++ )
+		HIPCHK( hipEventCreate( &sc->ev[ i ] ) );
+	HIPCHK( hipMalloc( &sc->d_prog, sizeof( rmd_program_t ) ) );
+	HIPCHK( hipMemcpy( sc->d_prog, &sc->dprog, sizeof( rmd_program_t ), hipMemcpyHostToDevice ) );
+	HIPCHK( hipMalloc( &sc->d_counters, 2 * sizeof( unsigned long long ) ) );
+	if( efn != nullptr ){
+		std::vector<int16_t>	t16;
+		std::vector<int32_t>	tlkey;
+		build_tables16( efn, t16, tlkey );
+		HIPCHK( hipMalloc( &sc->d_t16, t16.size() * sizeof( int16_t ) ) );
+		HIPCHK( hipMemcpy( sc->d_t16, t16.data(), t16.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
+		HIPCHK( hipMalloc( &sc->d_tlkey, tlkey.size() * sizeof( int32_t ) ) );
+		HIPCHK( hipMemcpy( sc->d_tlkey, tlkey.data(), tlkey.size() * sizeof( int32_t ), hipMemcpyHostToDevice ) );
+		HIPCHK( hipMalloc( &sc->d_loginc, RMA_EFN_LOGINC * sizeof( int32_t ) ) );
+		HIPCHK( hipMemcpy( sc->d_loginc, efn->loginc, RMA_EFN_LOGINC * sizeof( int32_t ), hipMemcpyHostToDevice ) );
+		sc->have_efn = true;
+	}
+	hipDeviceProp_t	prop;
+	HIPCHK( hipGetDeviceProperties( &prop, device ) );
+	sc->grid_blocks = prop.multiProcessorCount * 8;
+	const char	*tt = getenv( "RNAMOTIF_TILE" );
+	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 256 )
+		sc->tile_t = atoi( tt );
+	sc->hit_cap = 1 << 20;
+	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
+	*out = sc;
+	return 0;
+}
+
+extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
+{
+	if( sc == nullptr )
+		return;
+	( void )hipSetDevice( sc->device );
+	( void )hipFree( sc->d_prog );
+	( void )hipFree( sc->d_t16 );
+	( void )hipFree( sc->d_tlkey );
+	( void )hipFree( sc->d_loginc );
+	( void )hipFree( sc->d_hits );
+	( void )hipFree( sc->d_counters );
+	for( int i = 0; i < 4; i++ )
+		if( sc->ev[ i ] )
+			( void )hipEventDestroy( sc->ev[ i ] );
+	if( sc->stream )
+		( void )hipStreamDestroy( sc->stream );
+	delete sc;
+}
+
+extern "C" int rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
+	rma_db_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	rma::PackedDb	pk;
+	for( int i = 0; i < n; i++ )
+		pk.add( seqs[ i ], slens[ i ] < 0 ? 0 : slens[ i ] );
+	rma_db	*db = new rma_db;
+	db->sc = sc;
+	db->n_seq = n;
+	db->total_bases = pk.total_bases;
+	db->strands = sc->prog.chk_both_strs ? 2 : 1;
+	std::vector<int64_t>	tile_start( size_t( n ) + 1, 0 );
+	const int	T = sc->tile_t;
+	for( int i = 0; i < n; i++ ){
+		int64_t	nsz = int64_t( pk.slen[ i ] ) - sc->prog.dminlen + 1;
+		int64_t	nt = nsz > 0 ? ( nsz + T - 1 ) / T : 0;
+		tile_start[ i + 1 ] = tile_start[ i ] + nt * db->strands;
+	}
+	db->n_tiles = tile_start[ n ];
+	HIPCHK( hipSetDevice( sc->device ) );
+	size_t	nc = std::max<size_t>( pk.codes.size(), 1 ), na = std::max<size_t>( pk.amask.size(), 1 );
+	HIPCHK( hipMalloc( &db->d_codes, nc * sizeof( uint32_t ) ) );
+	HIPCHK( hipMalloc( &db->d_amask, na * sizeof( uint32_t ) ) );
+	HIPCHK( hipMalloc( &db->d_base_off, std::max<size_t>( n, 1 ) * sizeof( int64_t ) ) );
+	HIPCHK( hipMalloc( &db->d_slen, std::max<size_t>( n, 1 ) * sizeof( int32_t ) ) );
+	HIPCHK( hipMalloc( &db->d_tile_start, ( size_t( n ) + 1 ) * sizeof( int64_t ) ) );
+	if( !pk.codes.empty() ){
+		HIPCHK( hipMemcpy( db->d_codes, pk.codes.data(), pk.codes.size() * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
+		HIPCHK( hipMemcpy( db->d_amask, pk.amask.data(), pk.amask.size() * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
+	}
+	if( n > 0 ){
+		HIPCHK( hipMemcpy( db->d_base_off, pk.base_off.data(), size_t( n ) * sizeof( int64_t ), hipMemcpyHostToDevice ) );
+		HIPCHK( hipMemcpy( db->d_slen, pk.slen.data(), size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
+	}
+	HIPCHK( hipMemcpy( db->d_tile_start, tile_start.data(), tile_start.size() * sizeof( int64_t ), hipMemcpyHostToDevice ) );
+	*out = db;
+	return 0;
+}
+
+extern "C" void rma_db_destroy( rma_db_t *db )
+{
+	if( db == nullptr )
+		return;
+	( void )hipSetDevice( db->sc->device );
+	( void )hipFree( db->d_codes );
+	( void )hipFree( db->d_amask );
+	( void )hipFree( db->d_base_off );
+	( void )hipFree( db->d_slen );
+	( void )hipFree( db->d_tile_start );
+	delete db;
+}
+
+extern "C" int64_t rma_db_bases( const rma_db_t *db ) { return db->total_bases; }
+
+static DbView view_of( const rma_scanner *sc, const rma_db *db )
+{
+	DbView	v;
+	v.codes = db->d_codes;
+	v.amask = db->d_amask;
+	v.base_off = db->d_base_off;
+	v.slen = db->d_slen;
+	v.tile_start = db->d_tile_start;
+	v.n_seq = db->n_seq;
+	v.strands = db->strands;
+	v.tile_t = sc->tile_t;
+	v.n_tiles = db->n_tiles;
+	return v;
+}
+
+extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
+	float *efn_ms, char *err, size_t errlen )
+{
+	constexpr int	BLOCK = 256;
+	HIPCHK( hipSetDevice( sc->device ) );
+	*n_hits = 0;
+	if( search_ms ) *search_ms = 0;
+	if( efn_ms ) *efn_ms = 0;
+	if( db->n_tiles == 0 )
+		return 0;
+	DbView	v = view_of( sc, db );
+	const rmd_program_t	&dp = sc->dprog;
+	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
+	size_t	lds = PROG_LDS_BYTES + size_t( tile_bytes );
+	if( lds > 150 * 1024 ){
+		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
+		return 1;
+	}
+	HIPCHK( hipFuncSetAttribute( reinterpret_cast<const void *>( &rma_search_kernel<BLOCK> ),
+		hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	int	grid = int( std::min<int64_t>( db->n_tiles, sc->grid_blocks ) );
+	unsigned long long	count = 0;
+	for( int attempt = 0; attempt < 2; attempt++ ){
+		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 2 * sizeof( unsigned long long ), sc->stream ) );
+		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap };
+		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
+		hipLaunchKernelGGL( rma_search_kernel<BLOCK>, dim3( grid ), dim3( BLOCK ), lds, sc->stream,
+			sc->d_prog, v, hb, tile_bytes );
+		HIPCHK( hipGetLastError() );
+		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
+		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );
+		HIPCHK( hipStreamSynchronize( sc->stream ) );
+		if( int64_t( count ) <= sc->hit_cap )
+			break;
+		if( attempt == 1 ){
+			snprintf( err, errlen, "hit buffer overflow after regrow (%llu candidates)", count );
+			return 1;
+		}
+		// count-then-emit: the first pass told us how many records there are
+		( void )hipFree( sc->d_hits );
+		sc->d_hits = nullptr;
+		sc->hit_cap = int64_t( count ) + 1024;
+		HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * dp.hit_stride * sizeof( int32_t ) ) );
+	}
+	if( search_ms )
+		HIPCHK( hipEventElapsedTime( search_ms, sc->ev[ 0 ], sc->ev[ 1 ] ) );
+	*n_hits = int64_t( count );
+	if( sc->have_efn && dp.n_efn > 0 && count > 0 ){
+		constexpr int	EB = 64;
+		int64_t	blocks = ( int64_t( count ) + EB - 1 ) / EB;
+		HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
+		hipLaunchKernelGGL( rma_efn_kernel<EB>, dim3( unsigned( blocks ) ), dim3( EB ), 0, sc->stream,
+			sc->d_prog, v, sc->d_hits, ( long long )count, sc->d_t16, sc->d_tlkey, sc->d_loginc );
+		HIPCHK( hipGetLastError() );
+		HIPCHK( hipEventRecord( sc->ev[ 3 ], sc->stream ) );
+		HIPCHK( hipStreamSynchronize( sc->stream ) );
+		if( efn_ms )
+			HIPCHK( hipEventElapsedTime( efn_ms, sc->ev[ 2 ], sc->ev[ 3 ] ) );
+	}
+	return 0;
+}
+
+extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **hits, int64_t *n_hits,
+	char *err, size_t errlen )
+{
+	*hits = nullptr;
+	int64_t	n = 0;
+	if( rma_scan_device( sc, db, &n, nullptr, nullptr, err, errlen ) )
+		return 1;
+	*n_hits = n;
+	if( n == 0 )
+		return 0;
+	const int	stride = sc->dprog.hit_stride;
+	sc->h_raw.resize( size_t( n ) * stride );
+	HIPCHK( hipMemcpy( sc->h_raw.data(), sc->d_hits, sc->h_raw.size() * sizeof( int32_t ), hipMemcpyDeviceToHost ) );
+	// reference order: (seq, comp, szero, rank, order)
+	std::vector<int64_t>	idx( n );
+	std::iota( idx.begin(), idx.end(), 0 );
+	const int32_t	*d = sc->h_raw.data();
+	std::sort( idx.begin(), idx.end(), [ & ]( int64_t a, int64_t b ){
+		const int32_t	*x = d + a * stride, *y = d + b * stride;
+		for( int k = 0; k < RMA_HIT_HDR; k++ )
+			if( x[ k ] != y[ k ] )
+				return x[ k ] < y[ k ];
+		return false;
+	} );
+	sc->h_sorted.resize( sc->h_raw.size() );
+	for( int64_t i = 0; i < n; i++ )
+		memcpy( &sc->h_sorted[ size_t( i ) * stride ], d + idx[ i ] * stride, stride * sizeof( int32_t ) );
+	*hits = sc->h_sorted.data();
+	return 0;
+}

@@ -1,0 +1,113 @@
+// hostsim_check.cpp -- TEST INFRASTRUCTURE.
+//
+// Compiles the device search state machine (rnamotif_amd/csrc/rm_scan_core.h)
+// for the CPU and checks it, record by record, against the scalar oracle
+// (oracle/rm_oracle_scan.c) on a FASTA file.  This is how the state machine is
+// debugged in a container without a GPU; the package never loads it.
+//
+//   hostsim_check [rnamotif options] -descr file.descr db.fastn
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "rm_cli.h"
+#include "rm_oracle.h"
+#define RMD_FN static inline
+#include "rm_scan_core.h"
+
+struct VecSink {
+	std::vector<int32_t>	*out;
+	int	seq, comp, stride;
+	void put( const rmd_program_t *P, const rmd_lane_t *L, int szero )
+	{
+		size_t	o = out->size();
+		out->resize( o + stride );
+		rmd_fill_hit( P, L, seq, comp, szero, out->data() + o );
+	}
+};
+
+static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int slen, int comp, std::vector<int32_t> &out )
+{
+	std::vector<uint8_t>	codes( slen + 1 );
+	for( int i = 0; i < slen; i++ ){
+		switch( sbuf[ i ] ){
+		case 'a' : codes[ i ] = 0; break;
+		case 'c' : codes[ i ] = 1; break;
+		case 'g' : codes[ i ] = 2; break;
+		case 't' : case 'u' : codes[ i ] = 3; break;
+		default : codes[ i ] = 4; break;
+		}
+	}
+	rmd_seq_t	sq{ codes.data(), 0 };
+	rmd_lane_t	lane;
+	VecSink	sink{ &out, seq, comp, dp->hit_stride };
+	for( int szero = 0; szero <= slen - dp->dminlen; szero++ )
+		rmd_search_position( dp, &lane, sq, szero, slen, sink );
+}
+
+int main( int argc, char **argv )
+{
+	try{
+		rma::Args	args = rma::parse_args( argc, argv );
+		rma::Prepared	pr = rma::prepare( args );
+		fprintf( stderr, "%s: %d elements, %d searches, stride %d\n", args.dfname.c_str(),
+			pr.prog->n_elems, pr.prog->n_searches, rma_hit_stride( pr.prog.get() ) );
+		rmd_program_t	dp;
+		char	err[ 512 ];
+		if( rmd_build( pr.prog.get(), &dp, err, sizeof( err ) ) ){
+			fprintf( stderr, "rmd_build: %s\n", err );
+			return 2;
+		}
+		int	stride = dp.hit_stride, n_cmp = rma_hit_efn_off( pr.prog.get() );
+		int64_t	total = 0, bad = 0;
+		int	seq = 0;
+		for( const std::string &fn : args.dbfnames ){
+			FILE	*fp = fopen( fn.c_str(), "r" );
+			if( !fp ){ perror( fn.c_str() ); return 2; }
+			rma::FastaReader	rd( fp );
+			rma::SeqRecord	rec;
+			while( rd.next( rec ) ){
+				std::vector<char>	buf( rec.seq.begin(), rec.seq.end() );
+				buf.push_back( 0 );
+				int	slen = int( rec.seq.size() );
+				for( int comp = 0; comp < ( pr.prog->chk_both_strs ? 2 : 1 ); comp++ ){
+					if( comp )
+						rmo_revcomp( buf.data(), slen );
+					rmo_hits_t	oh;
+					rmo_hits_init( &oh, pr.prog.get() );
+					rmo_scan( pr.prog.get(), nullptr, seq, buf.data(), slen, comp, &oh );
+					std::vector<int32_t>	sh;
+					sim_scan( &dp, seq, buf.data(), slen, comp, sh );
+					int64_t	ns = int64_t( sh.size() ) / stride;
+					total += oh.n;
+					if( ns != oh.n ){
+						if( bad < 10 )
+							fprintf( stderr, "seq %d (%s) comp %d: oracle %lld hits, sim %lld\n", seq, rec.sid.c_str(), comp, ( long long )oh.n, ( long long )ns );
+						bad++;
+					}
+					for( int64_t h = 0; h < std::min( ns, oh.n ); h++ ){
+						if( memcmp( oh.data + h * stride, sh.data() + h * stride, n_cmp * sizeof( int32_t ) ) ){
+							if( bad < 10 ){
+								fprintf( stderr, "seq %d (%s) comp %d hit %lld differs:\n  oracle:", seq, rec.sid.c_str(), comp, ( long long )h );
+								for( int k = 0; k < n_cmp; k++ ) fprintf( stderr, " %d", oh.data[ h * stride + k ] );
+								fprintf( stderr, "\n  sim   :" );
+								for( int k = 0; k < n_cmp; k++ ) fprintf( stderr, " %d", sh[ h * stride + k ] );
+								fprintf( stderr, "\n" );
+							}
+							bad++;
+							break;
+						}
+					}
+					rmo_hits_free( &oh );
+				}
+				seq++;
+			}
+			fclose( fp );
+		}
+		printf( "%s: %lld candidates, %lld mismatching strands\n", args.dfname.c_str(), ( long long )total, ( long long )bad );
+		return bad ? 1 : 0;
+	}catch( rma::Error &e ){
+		fprintf( stderr, "%s\n", e.what() );
+		return 2;
+	}
+}

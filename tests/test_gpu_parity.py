@@ -1,0 +1,113 @@
+"""GPU parity: the HIP scanner, called through the C ABI, against the CPU
+oracle and the reference's pinned outputs.  Run on the MI355X box: -m gpu."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pins
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_cli(built, workdir, args):
+    env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    p = subprocess.run([built["cli"]] + args + ["gbrna.111.0.fastn"], cwd=workdir, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout
+
+
+@pytest.mark.parametrize("name", sorted(pins.SLACK))
+def test_cli_stdout_matches_reference_pin(built, workdir, name):
+    """`rnamotif -descr X gbrna.111.0.fastn` on the GPU: byte-identical stdout."""
+    out = _run_cli(built, workdir, ["-descr", name])
+    nhits, md5 = pins.SLACK[name]
+    assert out.count(b"\n>") + (1 if out.startswith(b">") else 0) == nhits
+    assert hashlib.md5(out).hexdigest() == md5
+
+
+@pytest.mark.parametrize("name", sorted(pins.STRICT))
+def test_cli_strict_stdout_matches_reference_pin(built, workdir, name):
+    out = _run_cli(built, workdir, pins.STRICT_ARGS + ["-descr", name + ".strict.descr"])
+    nhits, md5 = pins.STRICT[name]
+    assert hashlib.md5(out).hexdigest() == md5
+
+
+@pytest.mark.parametrize("name", ["trna.efn.descr", "pk1.descr", "qu+tr.descr", "mp.ends.descr",
+                                  "efn.descr", "getbest.descr", "pk_j1+2.descr"])
+def test_hit_records_equal_oracle(built, workdir, gbrna, name):
+    """Every candidate record (offsets, lengths, mispairs, mismatches, contexts,
+    efn energies) equals the oracle's, in the same order: bit exact."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        d = R.Descriptor(["-descr", name])
+    finally:
+        os.chdir(cwd)
+    recs = R.read_fasta(gbrna)
+    seqs = [r[2] for r in recs]
+    sc = R.Scanner(d)
+    db = sc.database(seqs)
+    got = sc.scan(db)
+    want = oracle_scan(d, seqs)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_ambiguity_and_short_sequences(built, workdir):
+    """Ragged input: empty, shorter than the motif, all-N, N-rich and mixed-case
+    IUPAC records; both strands."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(7)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    seqs = [b"", b"acgu".replace(b"u", b"t"), b"n" * 500]
+    for n in (19, 20, 21, 63, 64, 95, 96, 300, 5000, 70000):
+        s = bytearray(lut[rng.integers(0, 4, size=n)].tobytes())
+        for i in rng.integers(0, n, size=max(1, n // 37)):
+            s[i] = ord("nryswkm"[int(rng.integers(0, 7))])
+        seqs.append(bytes(s))
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        for name in ("mp.ends.descr", "trna.efn.descr", "pk1.descr"):
+            d = R.Descriptor(["-descr", name])
+            sc = R.Scanner(d)
+            got = sc.scan(sc.database(seqs))
+            want = oracle_scan(d, seqs)
+            assert np.array_equal(got, want), name
+    finally:
+        os.chdir(cwd)
+
+
+def test_syn10m_hit_counts(built, workdir):
+    """The synthetic database of BASELINE.md: candidates on the first 10 Mbase
+    equal the oracle's count; the reference reported 630 hits for trna."""
+    import rnamotif_amd as R
+    seqs = R.synthetic_records(10)
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        d = R.Descriptor(["-descr", "trna.efn.descr"])
+    finally:
+        os.chdir(cwd)
+    sc = R.Scanner(d)
+    hits = sc.scan(sc.database(seqs))
+    assert hits.shape[0] == pins.SYN10M["trna.efn.descr"]
+    # size independent properties: order, bounds, contiguity of the elements
+    key = hits[:, :5]
+    order = np.lexsort(key.T[::-1])
+    assert np.array_equal(order, np.arange(len(hits)))
+    off = hits[:, 5::4][:, :d.n_elems]
+    ln = hits[:, 6::4][:, :d.n_elems]
+    assert np.all(off[:, 1:] == off[:, :-1] + ln[:, :-1])
+    total = ln.sum(axis=1)
+    assert np.all((total >= d.minlen) & (total <= d.maxlen))
+    assert np.all(off[:, 0] == hits[:, 2])
