@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the scan path (BASELINE.json).
+
+One step = one pass of the hot path over one synthetic database that is already
+resident in HBM: search kernel over every start position of both strands, efn
+kernel over every candidate, copy back and ordering of the hit records
+(rma_scan of the C ABI).  Workload at N=1: descr/trna.descr (4-stem cloverleaf,
+bits()+efn() score) over the 100 Mbase synthetic FASTA of BASELINE.md
+(100 records x 1 Mbase, iid uniform acgt, numpy default_rng(20240601)).
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank scans its own 100 Mbase of the same synthetic stream (records
+[100*rank, 100*rank+100)), i.e. weak scaling; the hit records are gathered to
+rank 0 over RCCL inside the timed region, which is the path's only exchange.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_BASE = 0.375      # 2 bit code + 1 bit ambiguity mask, read once for both strands
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synthetic_slice(first: int, count: int, length: int):
+    """Records [first, first+count) of the synthetic stream (seed 20240601)."""
+    import numpy as np
+    rng = np.random.default_rng(20240601)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    out = []
+    for k in range(first + count):
+        v = rng.integers(0, 4, size=length)
+        if k >= first:
+            out.append(lut[v].tobytes())
+    return out
+
+
+def cpu_baseline(descr, seqs, budget_bases):
+    """The scalar CPU oracle (kind 'port': byte-identical to the reference on
+    its golden tests, and within a few percent of its speed here) on a bounded
+    sample of the same workload, one thread."""
+    from oracle_binding import oracle_scan
+    sample, got = [], 0
+    for s in seqs:
+        if got >= budget_bases:
+            break
+        take = s[: budget_bases - got]
+        sample.append(take)
+        got += len(take)
+    t0 = time.perf_counter()
+    hits = oracle_scan(descr, sample)
+    dt = time.perf_counter() - t0
+    return {"value": round(got / dt / 1e6, 4), "unit": "Mbases/s", "cores": 1, "kind": "port",
+            "sample": f"first {got} bases of the same database, both strands, {hits.shape[0]} candidates, {dt:.1f} s",
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--records", type=int, default=100, help="1 Mbase records per GPU (default 100 = 100 Mbase)")
+    ap.add_argument("--record-len", type=int, default=1_000_000)
+    ap.add_argument("--descr", default=os.path.join(ROOT, "tests", "golden", "descr", "trna.descr"))
+    ap.add_argument("--cpu-bases", type=int, default=12_000_000, help="sample size of the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import rnamotif_amd as R
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the scan path has no CPU implementation")
+    dev = torch.device("cuda", local_rank)
+
+    os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
+    descr = R.Descriptor(["-descr", args.descr])
+    seqs = synthetic_slice(rank * args.records, args.records, args.record_len)
+    sc = R.Scanner(descr, device=local_rank)
+    db = sc.database(seqs)
+    stride = descr.hit_stride
+
+    def gather_hits(h):
+        """Variable length gather of hit records to rank 0 (RCCL send/recv)."""
+        if world == 1:
+            return h
+        n = torch.tensor([h.shape[0]], dtype=torch.int64, device=dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, n)
+        counts = [int(c.item()) for c in counts]
+        if rank == 0:
+            parts = [h]
+            for r in range(1, world):
+                buf = torch.empty((counts[r], stride), dtype=torch.int32, device=dev)
+                if counts[r]:
+                    dist.recv(buf, src=r)
+                part = buf.cpu().numpy()
+                part[:, 0] += r * args.records          # sequence index within the whole job
+                parts.append(part)
+            return np.concatenate(parts, axis=0)
+        if h.shape[0]:
+            dist.send(torch.from_numpy(h).to(dev), dst=0)
+        return h
+
+    def step():
+        h = sc.scan(db)
+        return gather_hits(h)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    total_hits = 0
+    for _ in range(args.steps):
+        total_hits = step().shape[0]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # kernel time of the dominant kernel, HIP events on the scanner's own stream
+    kms = []
+    for _ in range(max(1, min(args.steps, 3))):
+        n_cand, search_ms, efn_ms = sc.scan_device(db)
+        kms.append((search_ms, efn_ms))
+    search_ms = float(np.mean([k[0] for k in kms]))
+    efn_ms = float(np.mean([k[1] for k in kms]))
+
+    if rank == 0:
+        bases_per_gpu = db.bases
+        total_bases = bases_per_gpu * world
+        ms_per_step = dt / args.steps * 1e3
+        value = total_bases / (dt / args.steps) / 1e6
+        achieved = ALGO_BYTES_PER_BASE * bases_per_gpu / (search_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mbases scanned/sec (whole node) + hits/sec, trna.descr",
+            "value": round(value, 3),
+            "unit": "Mbases/s",
+            "hits_per_s": round(total_hits / (dt / args.steps), 2),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{os.path.basename(args.descr)} (descr/trna.descr: 15 elements, bits()+efn() score) over "
+                            f"{args.records} x {args.record_len} base synthetic records per GPU "
+                            f"(iid uniform acgt, numpy default_rng(20240601)), both strands",
+                "bases_per_gpu": bases_per_gpu,
+                "total_bases": total_bases,
+                "candidates": total_hits,
+                "parallelism": f"{world} rank(s), sequences sharded, RCCL gather of hit records" if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "rma_search_kernel",
+                "achieved": round(achieved, 4),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 8),
+                "traffic": None,
+                "kernel_ms": round(search_ms, 3),
+                "efn_kernel_ms": round(efn_ms, 3),
+                "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE,
+                "note": "the search is integer/LDS issue bound, not HBM bound (SURVEY.md 8d); "
+                        "kernel-only rate = %.1f Mbases/s" % (bases_per_gpu / (search_ms * 1e-3) / 1e6),
+            },
+        }
+        if world == 1 and args.cpu_bases > 0:
+            out["cpu_baseline"] = cpu_baseline(descr, seqs, args.cpu_bases)
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -354,6 +354,36 @@ RMD_FN int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq
 	return 1;
 }
 
+// Does match_wchlx( s5, s3 ) have any candidate, seq= constraints aside?  A
+// superset test for the pre-filter pass: same pairing, end and pairfrac rules
+// (find_motif.c:1010-1109), no state written.
+RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const rmd_seq_t &sq, int s5, int s3, int s3lim )
+{
+	if( stp.minlen == 0 )
+		return 1;
+	int	hl = 1, mpr = 0, l_bpr = 1;
+	if( !rmd_paired( P, stp.pairset, rmd_code( sq, s5 ), rmd_code( sq, s3 ) ) ){
+		if( stp.ends & RMA_5PAIRED )
+			return 0;
+		mpr = 1;
+		l_bpr = 0;
+	}
+	for( ; ; ){
+		if( hl >= stp.minlen && ( l_bpr || !( stp.ends & RMA_3PAIRED ) ) && ( !stp.pfrac || mpr <= stp.pf_maxmpr[ hl ] ) )
+			return 1;
+		if( !( s3 - hl + 1 >= s3lim ) || hl >= stp.maxlen )
+			return 0;
+		if( rmd_paired( P, stp.pairset, rmd_code( sq, s5 + hl ), rmd_code( sq, s3 - hl ) ) )
+			l_bpr = 1;
+		else{
+			if( ++mpr > stp.mplim )
+				return 0;
+			l_bpr = 0;
+		}
+		hl++;
+	}
+}
+
 // ---------------------------------------------------------------- terminal checks
 // fm_window[] lookup (find_motif.c:1333-1385 marks): type of the element that
 // covers position pos, RMA_T_SS when nothing does and undef_is_ss, else -1.
@@ -933,9 +963,24 @@ RMD_FN void rmd_fill_hit( const rmd_program_t *P, const rmd_lane_t *L, int seq, 
 
 // The search for one start position (one iteration of RM_find_motif's loops,
 // find_motif.c:184-205).  Sink::put( lane ) stores the candidate.
+// Range of end positions of the first search element at start szero
+// (find_motif.c:266-269 with RM_find_motif's window, :179-205): hi downto lo.
+RMD_FN void rmd_level0_range( const rmd_program_t *P, int szero, int slen, int *hi, int *lo )
+{
+	const rmd_elem_t	&stp = P->elems[ P->searches[ 0 ] ];
+	int	d0 = rmd_imin( szero + P->w_winsize - 1, slen - 1 );
+	if( stp.maxglen != RMA_UNBOUNDED && szero + stp.maxglen - 1 < d0 )
+		d0 = szero + stp.maxglen - 1;
+	*hi = d0;
+	*lo = szero + stp.minglen - 1;
+}
+
+// r0/cnt select which end positions of the first element are searched: ranks
+// r0 .. r0+cnt-1 counted from the largest; ( 0, RMD_ALL_RANKS ) is the whole position.
+#define RMD_ALL_RANKS	0x7fffffff
 template< class Sink >
 RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int szero, int slen, Sink &sink )
+	int szero, int slen, int r0, int cnt, Sink &sink )
 {
 	for( int i = 0; i < P->n_elems; i++ ){
 		L->moff[ i ] = L->mlen[ i ] = RMD_UNDEF;
@@ -951,6 +996,15 @@ RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rm
 	const int	last = P->n_searches - 1;
 	int	k = 0;
 	rmd_enter( P, L, 0 );
+	if( r0 > 0 || cnt != RMD_ALL_RANKS ){
+		rmd_frame_t	&f0 = L->fr[ 0 ];
+		int	hi = f0.sd - r0;
+		int	lo = cnt >= f0.sd - f0.sd_lo + 1 ? f0.sd_lo : hi - cnt + 1;
+		f0.sd = hi;
+		if( lo > f0.sd_lo )
+			f0.sd_lo = lo;
+		L->rank = r0 - 1;
+	}
 	while( k >= 0 ){
 		if( !rmd_next( P, L, sq, k ) ){
 			k--;

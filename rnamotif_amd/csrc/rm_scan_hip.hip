@@ -74,6 +74,7 @@ struct DevSink {
 };
 
 #define PROG_LDS_BYTES	( ( sizeof( rmd_program_t ) + 15 ) & ~size_t( 15 ) )
+#define QCAP		8192		// work queue entries per workgroup
 
 // ---------------------------------------------------------------- search kernel
 template< int BLOCK >
@@ -82,9 +83,10 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 {
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
-	uint8_t	*tile = smem + PROG_LDS_BYTES;
+	unsigned	*queue = reinterpret_cast<unsigned *>( smem + PROG_LDS_BYTES );
+	uint8_t	*tile = smem + PROG_LDS_BYTES + QCAP * sizeof( unsigned );
 	__shared__ long long	s_tile;
-	__shared__ int	s_seq;
+	__shared__ int	s_seq, s_qn;
 	const int	tid = threadIdx.x;
 
 	for( unsigned i = tid; i < sizeof( rmd_program_t ) / 4; i += BLOCK )
@@ -94,6 +96,14 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 	const int	T = db.tile_t;
 	const int	w = P->w_winsize, lm = P->lmargin, rm = P->rmargin;
 	rmd_lane_t	lane;
+
+	// pre-filter set-up: first search element a proper helix (find_wchlx) or a 4-plex
+	const rmd_elem_t	&e0 = P->elems[ P->searches[ 0 ] ];
+	int	i_minl0 = e0.minilen;
+	if( e0.type == RMA_T_Q1 )
+		i_minl0 += P->elems[ e0.mates[ 0 ] ].minilen + P->elems[ e0.mates[ 1 ] ].minilen + 2 * e0.minlen;
+	int	n_rank = ( e0.maxglen != RMA_UNBOUNDED && e0.maxglen < w ? e0.maxglen : w ) - e0.minglen + 1;
+	const bool	quick = ( ( e0.type == RMA_T_H5 && e0.proper ) || e0.type == RMA_T_Q1 ) && n_rank < 0xffff;
 
 	for( ; ; ){
 		if( tid == 0 ){
@@ -113,6 +123,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			}
 			s_tile = t;
 			s_seq = s;
+			s_qn = 0;
 		}
 		__syncthreads();
 		const long long	t = s_tile;
@@ -136,11 +147,64 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			tile[ p - p_lo ] = uint8_t( db_strand_code( db, off, slen, comp, p ) );
 		__syncthreads();
 
-		const int	szero = z0 + tid;
-		if( tid < T && szero <= slen - P->dminlen ){
-			rmd_seq_t	sq{ tile, p_lo };
-			DevSink	sink{ hb, seq, comp, P->hit_stride };
-			rmd_search_position( P, &lane, sq, szero, slen, sink );
+		// ---- pass A: pre-filter.  Where the first search element is a proper helix
+		// or a 4-plex, almost every (start, end) pair dies at its first base pairs
+		// (find_motif.c:1010-1021); test that here in registers, no search state,
+		// and compact the survivors into the LDS work queue with one wave ballot +
+		// prefix count per step.  Other first elements queue the whole position.
+		rmd_seq_t	sq{ tile, p_lo };
+		DevSink	sink{ hb, seq, comp, P->hit_stride };
+		const int	lane_id = tid & 63;
+		const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
+		for( int j = 0; j < T; j += BLOCK ){
+			const int	rel = j + tid;
+			const int	szero = z0 + rel;
+			const bool	valid = rel < T && szero <= slen - P->dminlen;
+			int	hi = 0, lo = 1;
+			if( valid && quick )
+				rmd_level0_range( P, szero, slen, &hi, &lo );
+			const int	steps = quick ? n_rank : 1;
+			for( int r = 0; r < steps; r++ ){
+				bool	pred;
+				unsigned	item;
+				if( quick ){
+					const int	sd = hi - r;
+					pred = valid && sd >= lo &&
+						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) );
+					item = ( unsigned( rel ) << 16 ) | unsigned( r );
+				}else{
+					pred = valid;
+					item = ( unsigned( rel ) << 16 ) | 0xffffu;
+				}
+				const unsigned long long	m = __ballot( pred );
+				if( m == 0 )
+					continue;
+				int	base = 0;
+				if( lane_id == __ffsll( ( unsigned long long )m ) - 1 )
+					base = atomicAdd( &s_qn, __popcll( m ) );
+				base = __shfl( base, __ffsll( ( unsigned long long )m ) - 1 );
+				if( pred ){
+					const int	slot = base + __popcll( m & lt_mask );
+					if( slot < QCAP )
+						queue[ slot ] = item;
+					else	// queue full: search it right here
+						rmd_search_position( P, &lane, sq, szero, slen, quick ? r : 0,
+							quick ? 1 : RMD_ALL_RANKS, sink );
+				}
+			}
+		}
+		__syncthreads();
+
+		// ---- pass B: the full search, one queued item per lane
+		const int	nq = s_qn < QCAP ? s_qn : QCAP;
+		for( int i = tid; i < nq; i += BLOCK ){
+			const unsigned	item = queue[ i ];
+			const int	szero = z0 + int( item >> 16 );
+			const int	r = int( item & 0xffffu );
+			if( r == 0xffff )
+				rmd_search_position( P, &lane, sq, szero, slen, 0, RMD_ALL_RANKS, sink );
+			else
+				rmd_search_position( P, &lane, sq, szero, slen, r, 1, sink );
 		}
 		__syncthreads();
 	}
@@ -193,7 +257,7 @@ struct rma_scanner {
 	int64_t	hit_cap = 0;
 	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
 	std::vector<int32_t>	h_raw, h_sorted;
-	int	tile_t = 256;
+	int	tile_t = 2048;
 	int	grid_blocks = 0;
 };
 
@@ -301,7 +365,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	HIPCHK( hipGetDeviceProperties( &prop, device ) );
 	sc->grid_blocks = prop.multiProcessorCount * 8;
 	const char	*tt = getenv( "RNAMOTIF_TILE" );
-	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 256 )
+	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 16384 )
 		sc->tile_t = atoi( tt );
 	sc->hit_cap = 1 << 20;
 	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
@@ -411,7 +475,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	DbView	v = view_of( sc, db );
 	const rmd_program_t	&dp = sc->dprog;
 	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	size_t	lds = PROG_LDS_BYTES + size_t( tile_bytes );
+	size_t	lds = PROG_LDS_BYTES + QCAP * sizeof( unsigned ) + size_t( tile_bytes );
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;

@@ -8,6 +8,7 @@
 //   hostsim_check [rnamotif options] -descr file.descr db.fastn
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "rm_cli.h"
@@ -41,8 +42,26 @@ static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int sl
 	rmd_seq_t	sq{ codes.data(), 0 };
 	rmd_lane_t	lane;
 	VecSink	sink{ &out, seq, comp, dp->hit_stride };
-	for( int szero = 0; szero <= slen - dp->dminlen; szero++ )
-		rmd_search_position( dp, &lane, sq, szero, slen, sink );
+	// same decomposition as the kernel: a pre-filter over the end positions of the
+	// first element where it is a proper helix or a 4-plex, one item per survivor
+	const rmd_elem_t	&e0 = dp->elems[ dp->searches[ 0 ] ];
+	bool	quick = ( e0.type == RMA_T_H5 && e0.proper ) || e0.type == RMA_T_Q1;
+	int	i_minl0 = e0.minilen;
+	if( e0.type == RMA_T_Q1 )
+		i_minl0 += dp->elems[ e0.mates[ 0 ] ].minilen + dp->elems[ e0.mates[ 1 ] ].minilen + 2 * e0.minlen;
+	for( int szero = 0; szero <= slen - dp->dminlen; szero++ ){
+		if( !quick || getenv( "HOSTSIM_NOQUICK" ) ){
+			rmd_search_position( dp, &lane, sq, szero, slen, 0, RMD_ALL_RANKS, sink );
+			continue;
+		}
+		int	hi, lo;
+		rmd_level0_range( dp, szero, slen, &hi, &lo );
+		for( int sd = hi; sd >= lo; sd-- ){
+			int	s3lim = rmd_s3lim( szero, sd, i_minl0, e0.maxlen );
+			if( rmd_quick_wchlx( dp, e0, sq, szero, sd, s3lim ) )
+				rmd_search_position( dp, &lane, sq, szero, slen, hi - sd, 1, sink );
+		}
+	}
 }
 
 int main( int argc, char **argv )
