@@ -79,7 +79,7 @@ struct DevSink {
 // ---------------------------------------------------------------- search kernel
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK )
-rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes )
+rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int dbg )
 {
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
@@ -196,7 +196,9 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		__syncthreads();
 
 		// ---- pass B: the full search, one queued item per lane
-		const int	nq = s_qn < QCAP ? s_qn : QCAP;
+		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < QCAP ? s_qn : QCAP );
+		if( ( dbg & 2 ) && tid == 0 )
+			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
 		for( int i = tid; i < nq; i += BLOCK ){
 			const unsigned	item = queue[ i ];
 			const int	szero = z0 + int( item >> 16 );
@@ -208,7 +210,6 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		}
 		__syncthreads();
 	}
-	( void )tile_bytes;
 }
 
 // ---------------------------------------------------------------- efn kernel
@@ -348,7 +349,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		HIPCHK( hipEventCreate( &sc->ev[ i ] ) );
 	HIPCHK( hipMalloc( &sc->d_prog, sizeof( rmd_program_t ) ) );
 	HIPCHK( hipMemcpy( sc->d_prog, &sc->dprog, sizeof( rmd_program_t ), hipMemcpyHostToDevice ) );
-	HIPCHK( hipMalloc( &sc->d_counters, 2 * sizeof( unsigned long long ) ) );
+	HIPCHK( hipMalloc( &sc->d_counters, 4 * sizeof( unsigned long long ) ) );
 	if( efn != nullptr ){
 		std::vector<int16_t>	t16;
 		std::vector<int32_t>	tlkey;
@@ -485,15 +486,20 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	int	grid = int( std::min<int64_t>( db->n_tiles, sc->grid_blocks ) );
 	unsigned long long	count = 0;
 	for( int attempt = 0; attempt < 2; attempt++ ){
-		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 2 * sizeof( unsigned long long ), sc->stream ) );
+		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 4 * sizeof( unsigned long long ), sc->stream ) );
 		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		hipLaunchKernelGGL( rma_search_kernel<BLOCK>, dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-			sc->d_prog, v, hb, tile_bytes );
+			sc->d_prog, v, hb, getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0 );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );
 		HIPCHK( hipStreamSynchronize( sc->stream ) );
+		if( getenv( "RNAMOTIF_DBG" ) ){
+			unsigned long long	q = 0;
+			( void )hipMemcpy( &q, sc->d_counters + 2, sizeof( q ), hipMemcpyDeviceToHost );
+			fprintf( stderr, "[dbg] queued items: %llu, candidates %llu\n", q, count );
+		}
 		if( int64_t( count ) <= sc->hit_cap )
 			break;
 		if( attempt == 1 ){

@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads and exports every function include/rnamotif_amd.h
+declares; the front-end half works without a GPU and the scanner half refuses
+to run without one (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rnamotif_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rma_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(built):
+    lib = ctypes.CDLL(built["lib"])
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_front_end_without_gpu_and_loud_failure(built):
+    import rnamotif_amd as R
+    d = R.Descriptor(["-descr", os.path.join(ROOT, "tests", "golden", "descr", "trna.descr")])
+    assert (d.n_elems, d.n_searches, d.minlen, d.maxlen, d.n_efn_sites) == (15, 11, 63, 95, 1)
+    assert d.hit_stride == 5 + 4 * 15 + 4 + 1
+    if R.lib().rma_device_count() == 0:
+        with pytest.raises(R.RnamotifError, match="GPU only"):
+            R.Scanner(d)
+
+
+def test_descriptor_errors_are_reported_not_fatal(built, tmp_path):
+    import rnamotif_amd as R
+    bad = tmp_path / "bad.descr"
+    bad.write_text("descr\n\th5( minlen=3 ) ss( len=4 )\n")          # h5 without h3
+    with pytest.raises(R.RnamotifError, match="no matching"):
+        R.Descriptor(["-descr", str(bad)])
+    bad.write_text("descr\n\th5 ss( h3\n")
+    with pytest.raises(R.RnamotifError, match="syntax error"):
+        R.Descriptor(["-descr", str(bad)])
+    with pytest.raises(R.RnamotifError):
+        R.Descriptor(["-descr", str(tmp_path / "missing.descr")])

@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: sequence sharding + variable length gather of
+hit records (rnamotif_amd/distributed.py) give rank 0 exactly the records, in
+exactly the order, of a single-process scan.  The scan itself is done by the
+oracle here (no GPU in this container); on GPUs bench.py runs the same gather
+over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import rnamotif_amd as R
+from rnamotif_amd.distributed import partition_by_bases, gather_hits
+from oracle_binding import oracle_scan
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+d = R.Descriptor(["-descr", os.path.join(sys.argv[1], "tests", "golden", "test", "sprintf.descr")])
+rng = np.random.default_rng(11)
+lut = np.frombuffer(b"acgt", dtype=np.uint8)
+seqs = [lut[rng.integers(0, 4, size=int(n))].tobytes() for n in (30000, 5, 12000, 0, 26000, 9000, 41000)]
+parts = partition_by_bases([len(s) for s in seqs], world)
+mine = parts[rank]
+local = oracle_scan(d, [seqs[i] for i in mine])
+allh = gather_hits(local, mine, d.hit_stride)
+if rank == 0:
+    want = oracle_scan(d, seqs)
+    assert sorted(sum(parts, [])) == list(range(len(seqs)))
+    assert allh.shape == want.shape and np.array_equal(allh, want), (allh.shape, want.shape)
+    np.save(sys.argv[2], allh)
+else:
+    assert allh.shape[0] == 0
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_and_gather_world2(built, tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "hits.npy"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
+    hits = np.load(out)
+    assert hits.shape[0] > 0
+
+
+def test_partition_balances_and_keeps_order():
+    from rnamotif_amd.distributed import partition_by_bases
+    lens = [1000, 10, 900, 50, 800, 5, 700]
+    parts = partition_by_bases(lens, 3)
+    assert sorted(sum(parts, [])) == list(range(len(lens)))
+    loads = [sum(lens[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(lens)
+    assert all(p == sorted(p) for p in parts)

@@ -1,0 +1,41 @@
+"""CPU: the device search state machine (rm_scan_core.h, the code the HIP kernel
+runs per lane, including the pre-filter decomposition) compiled for the host and
+compared with the oracle record by record on the reference's test database."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "_build", "hostsim_check")
+H = os.path.join(ROOT, "rnamotif_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def hostsim():
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    srcs = [os.path.join(ROOT, "tests", "hostsim", "hostsim_check.cpp")]
+    srcs += [os.path.join(H, f) for f in ("rm_regex.cpp", "rm_compile.cpp", "rm_parse.cpp", "rm_score.cpp",
+                                          "rm_efndata.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp",
+                                          "rm_dev_program.cpp")]
+    srcs += [os.path.join(ROOT, "oracle", f) for f in ("rm_oracle_scan.c", "rm_oracle_efn.c")]
+    newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(H, "rm_scan_core.h")])
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < newest:
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + H,
+                        "-I" + os.path.join(ROOT, "oracle"), "-o", BIN] + srcs + ["-lm"], check=True)
+    return BIN
+
+
+CASES = [(["-descr", "trna.descr"], 1351), (["-descr", "mp.ends.descr"], 580), (["-descr", "qu+tr.descr"], 9),
+         (["-descr", "pk_j1+2.descr"], 32), (["-descr", "bulge.descr"], 686), (["-descr", "nanlin.descr"], 13),
+         (["-sh", "-context", "-Dctx_maxlen=5", "-descr", "qu+tr.strict.descr"], 9),
+         (["-sh", "-context", "-Dctx_maxlen=5", "-descr", "trna.strict.descr"], 184),
+         (["-sh", "-context", "-Dctx_maxlen=5", "-descr", "pk1.strict.descr"], 45)]
+
+
+@pytest.mark.parametrize("args,ncand", CASES, ids=[" ".join(c[0][-1:]) for c in CASES])
+def test_state_machine_equals_oracle(hostsim, workdir, args, ncand):
+    p = subprocess.run([hostsim] + args + ["gbrna.111.0.fastn"], cwd=workdir, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1800)
+    assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
+    assert (b"%d candidates, 0 mismatching strands" % ncand) in p.stdout
