@@ -131,6 +131,12 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		d->minilen = e.minilen;
 		d->maxilen = e.maxilen;
 		d->mismatch = e.mismatch;
+		d->quick = ( e.type == RMA_T_H5 && e.proper ) || e.type == RMA_T_Q1;
+		d->q_iminl = e.minilen;
+		if( e.type == RMA_T_Q1 )
+			d->q_iminl += p->elems[ e.mates[ 0 ] ].minilen + p->elems[ e.mates[ 1 ] ].minilen + 2 * e.minlen;
+		if( e.type == RMA_T_H5 && !e.proper )
+			out->need_init = 1;
 		// every strand of a helix carries the group's rules (match_4plex reads them from q2)
 		bool	helix = e.type != RMA_T_SS && e.type != RMA_T_CTX;
 		if( helix ){

@@ -11,7 +11,9 @@
 #include <cstdint>
 #include "rnamotif_amd_program.h"
 
+#ifndef RMD_MAX_ELEMS
 #define RMD_MAX_ELEMS	32	// elements (and search levels) per descriptor on the device
+#endif
 #define RMD_MAX_HLEN	63	// longest helix strand: candidate sets are 64-bit masks
 #define RMD_MAX_RE	34
 #define RMD_MAX_PS	40
@@ -48,7 +50,8 @@ struct rmd_elem_t {
 	int8_t	scopes[ 8 ];
 	int8_t	pairset, re;
 	int8_t	pfrac;			// pairfrac rule active
-	int8_t	pad;
+	int8_t	quick;			// level searched with match_wchlx at (zero, sdollar): proper h5, q1
+	int32_t	q_iminl;		// interior minimum of that match (find_motif.c:423,884)
 	int32_t	minlen, maxlen, minglen, maxglen, minilen, maxilen;
 	int32_t	mismatch;
 	int32_t	mplim;			// match_wchlx/match_phlx mispair limit
@@ -66,6 +69,7 @@ struct rmd_program_t {
 	int32_t	n_elems, n_searches;
 	int32_t	dminlen, w_winsize;	// min( dmaxlen, windowsize )
 	int32_t	strict_helices;
+	int32_t	need_init;		// some helix is improper: element state must start UNDEF
 	int32_t	has_lctx, has_rctx;
 	int32_t	n_sites, n_efn;
 	int32_t	efn_usestdbp, efn_stdbp;

@@ -23,6 +23,14 @@
 
 #define RMD_UNDEF	(-1)
 
+// host-only instrumentation for tests/hostsim (never defined in the kernel build)
+#ifdef RMD_STATS
+static long long	rmd_stat[ 16 ];
+#define RMD_COUNT( i )	( rmd_stat[ i ]++ )
+#else
+#define RMD_COUNT( i )	( ( void )0 )
+#endif
+
 struct rmd_frame_t {
 	int32_t	sd, sd_lo, o_sd;	// find_motif's sdollar loop: next value, last value, saved s_dollar
 	int32_t	ph;			// generator phase
@@ -38,7 +46,7 @@ struct rmd_lane_t {
 	int16_t	mpr[ RMD_MAX_ELEMS ], mm[ RMD_MAX_ELEMS ];	// s_n_mispairs/s_n_mismatches
 	rmd_frame_t	fr[ RMD_MAX_ELEMS ];
 	int32_t	l_off, l_len, r_off, r_len, l_mm, r_mm;
-	int32_t	slen;
+	int32_t	slen, szero, hi0;
 	int32_t	rank, order;
 };
 
@@ -158,6 +166,7 @@ RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq
 	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis )
 {
 	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
+	RMD_COUNT( 4 );
 	uint64_t	c = 0, m = 0;
 	int	hl, mpr, l_bpr, mm5 = L->mm[ d5 ], mm3 = L->mm[ d3 ];
 
@@ -610,16 +619,32 @@ RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
 	const rmd_elem_t	&stp = P->elems[ d ];
 	rmd_frame_t	&f = L->fr[ k ];
 
+	RMD_COUNT( 0 );
 	for( ; ; ){
+		RMD_COUNT( 1 );
 		if( f.ph == 0 ){
+			RMD_COUNT( 2 + ( stp.type == RMA_T_SS ? 0 : 1 ) );
 			// next end position of find_motif's loop
 			if( f.sd < f.sd_lo ){
 				L->dollar[ k ] = f.o_sd;
 				return 0;
 			}
+			if( stp.quick ){
+				// end positions whose first base pairs cannot start this helix are
+				// skipped without touching the search state (they have no effect
+				// that outlives the iteration, find_motif.c:273-280,1010-1021)
+				const int	z = L->zero[ k ];
+				while( f.sd >= f.sd_lo &&
+					!rmd_quick_wchlx( P, stp, sq, z, f.sd, rmd_s3lim( z, f.sd, stp.q_iminl, stp.maxlen ) ) )
+					f.sd--;
+				if( f.sd < f.sd_lo ){
+					L->dollar[ k ] = f.o_sd;
+					return 0;
+				}
+			}
 			if( stp.loop ){
 				if( k == 0 ){
-					L->rank++;
+					L->rank = L->hi0 - f.sd;
 					L->order = 0;
 				}
 				L->dollar[ k ] = f.sd;
@@ -978,24 +1003,28 @@ RMD_FN void rmd_level0_range( const rmd_program_t *P, int szero, int slen, int *
 // r0/cnt select which end positions of the first element are searched: ranks
 // r0 .. r0+cnt-1 counted from the largest; ( 0, RMD_ALL_RANKS ) is the whole position.
 #define RMD_ALL_RANKS	0x7fffffff
-template< class Sink >
-RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int szero, int slen, int r0, int cnt, Sink &sink )
+// Start the search of one work item: returns the level to run next (0).
+RMD_FN int rmd_search_begin( const rmd_program_t *P, rmd_lane_t *L, int szero, int slen, int r0, int cnt )
 {
-	for( int i = 0; i < P->n_elems; i++ ){
-		L->moff[ i ] = L->mlen[ i ] = RMD_UNDEF;
-		L->mpr[ i ] = L->mm[ i ] = RMD_UNDEF;
+	RMD_COUNT( 5 );
+	// without pseudoknots every element is written before it is read
+	// (find_minlen/find_maxlen are the only readers of unmatched elements)
+	if( P->need_init ){
+		for( int i = 0; i < P->n_elems; i++ ){
+			L->moff[ i ] = L->mlen[ i ] = RMD_UNDEF;
+			L->mpr[ i ] = L->mm[ i ] = RMD_UNDEF;
+		}
 	}
 	L->l_mm = L->r_mm = RMD_UNDEF;
 	L->l_off = L->l_len = L->r_off = L->r_len = 0;
 	L->slen = slen;
+	L->szero = szero;
 	L->rank = -1;
 	L->order = 0;
 	L->zero[ 0 ] = szero;
 	L->dollar[ 0 ] = rmd_imin( szero + P->w_winsize - 1, slen - 1 );
-	const int	last = P->n_searches - 1;
-	int	k = 0;
 	rmd_enter( P, L, 0 );
+	L->hi0 = L->fr[ 0 ].sd;
 	if( r0 > 0 || cnt != RMD_ALL_RANKS ){
 		rmd_frame_t	&f0 = L->fr[ 0 ];
 		int	hi = f0.sd - r0;
@@ -1005,24 +1034,39 @@ RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rm
 			f0.sd_lo = lo;
 		L->rank = r0 - 1;
 	}
-	while( k >= 0 ){
-		if( !rmd_next( P, L, sq, k ) ){
-			k--;
-			continue;
-		}
-		if( k < last ){
-			k++;
-			rmd_enter( P, L, k );
-			continue;
-		}
-		// end of the search list: find_ss :362-393
-		if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
-			continue;
-		if( !rmd_set_context( P, L, sq ) )
-			continue;
-		if( !rmd_chk_sites( P, L, sq ) )
-			continue;
-		sink.put( P, L, szero );
-		L->order++;
+	return 0;
+}
+
+// One transition of the search at level k; returns the next level, -1 when the
+// item is finished.  Sink::put( P, L, szero ) stores a candidate.
+template< class Sink >
+RMD_FN int rmd_search_step( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k, Sink &sink )
+{
+	if( !rmd_next( P, L, sq, k ) )
+		return k - 1;
+	if( k < P->n_searches - 1 ){
+		rmd_enter( P, L, k + 1 );
+		return k + 1;
 	}
+	// end of the search list: find_ss :362-393
+	if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
+		return k;
+	if( !rmd_set_context( P, L, sq ) )
+		return k;
+	if( !rmd_chk_sites( P, L, sq ) )
+		return k;
+	sink.put( P, L, L->szero );
+	L->order++;
+	return k;
+}
+
+// The search for one start position (one iteration of RM_find_motif's loops,
+// find_motif.c:184-205), restricted to ranks r0 .. r0+cnt-1 of the first element.
+template< class Sink >
+RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+	int szero, int slen, int r0, int cnt, Sink &sink )
+{
+	int	k = rmd_search_begin( P, L, szero, slen, r0, cnt );
+	while( k >= 0 )
+		k = rmd_search_step( P, L, sq, k, sink );
 }

@@ -79,14 +79,14 @@ struct DevSink {
 // ---------------------------------------------------------------- search kernel
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK )
-rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int dbg )
+rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
 	unsigned	*queue = reinterpret_cast<unsigned *>( smem + PROG_LDS_BYTES );
 	uint8_t	*tile = smem + PROG_LDS_BYTES + QCAP * sizeof( unsigned );
 	__shared__ long long	s_tile;
-	__shared__ int	s_seq, s_qn;
+	__shared__ int	s_seq, s_qn, s_qhead;
 	const int	tid = threadIdx.x;
 
 	for( unsigned i = tid; i < sizeof( rmd_program_t ) / 4; i += BLOCK )
@@ -104,6 +104,14 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int dbg )
 		i_minl0 += P->elems[ e0.mates[ 0 ] ].minilen + P->elems[ e0.mates[ 1 ] ].minilen + 2 * e0.minlen;
 	int	n_rank = ( e0.maxglen != RMA_UNBOUNDED && e0.maxglen < w ? e0.maxglen : w ) - e0.minglen + 1;
 	const bool	quick = ( ( e0.type == RMA_T_H5 && e0.proper ) || e0.type == RMA_T_Q1 ) && n_rank < 0xffff;
+	// helices that allow no mispair at all (find_motif.c:1010-1033 with mplim == 0) take
+	// the bit-parallel pre-filter
+	const bool	bitpar = quick && !( dbg & 4 ) && e0.mplim == 0 && !e0.pfrac && ( e0.ends & RMA_5PAIRED ) &&
+		e0.minlen >= 1;
+	const unsigned	e0_mat2 = quick ? P->pairsets[ e0.pairset ].mat2 : 0;
+	const int	pb_words = ( tile_bytes + 63 ) / 64 + 3;
+	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + PROG_LDS_BYTES + QCAP * sizeof( unsigned ) +
+		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
 
 	for( ; ; ){
 		if( tid == 0 ){
@@ -124,6 +132,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int dbg )
 			s_tile = t;
 			s_seq = s;
 			s_qn = 0;
+			s_qhead = 0;
 		}
 		__syncthreads();
 		const long long	t = s_tile;
@@ -156,6 +165,77 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int dbg )
 		DevSink	sink{ hb, seq, comp, P->hit_stride };
 		const int	lane_id = tid & 63;
 		const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
+		// push( pred, item ): one ballot + prefix count per call; overflow is searched in place
+#define QPUSH( pred, item, szero_, r0_, cnt_ )	do{ \
+		const unsigned long long	m_ = __ballot( pred ); \
+		if( m_ ){ \
+			int	base_ = 0; \
+			if( lane_id == __ffsll( m_ ) - 1 ) \
+				base_ = atomicAdd( &s_qn, __popcll( m_ ) ); \
+			base_ = __shfl( base_, __ffsll( m_ ) - 1 ); \
+			if( pred ){ \
+				const int	slot_ = base_ + __popcll( m_ & lt_mask ); \
+				if( slot_ < QCAP ) \
+					queue[ slot_ ] = ( item ); \
+				else \
+					rmd_search_position( P, &lane, sq, szero_, slen, r0_, cnt_, sink ); \
+			} \
+		} }while( 0 )
+
+		if( bitpar ){
+			// Bit-parallel form for helices without mispairs: pb[ b ] has a bit per tile
+			// position that can pair with 5' base b, so "the first minlen pairs of
+			// (start, end) all pair" is an AND of minlen shifted 64-bit windows, 64 end
+			// positions at a time.
+			const int	n_valid = p_to - p_lo;
+			for( int base = ( tid >> 6 ) * 64; base < pb_words * 64; base += BLOCK ){
+				const int	q = base + lane_id - 64;		// one pad word in front
+				const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
+				for( int b5 = 0; b5 < 5; b5++ ){
+					const unsigned long long	m = __ballot( code < 5 && ( ( e0_mat2 >> ( b5 * 5 + code ) ) & 1 ) );
+					if( lane_id == b5 )
+						pb[ b5 * pb_words + ( base >> 6 ) ] = m;
+				}
+			}
+			__syncthreads();
+			const int	hl0 = e0.minlen;
+			for( int j = 0; j < T; j += BLOCK ){
+				const int	rel = j + tid;
+				const int	szero = z0 + rel;
+				const bool	valid = rel < T && szero <= slen - P->dminlen;
+				int	hi = 0, lo = 1;
+				if( valid )
+					rmd_level0_range( P, szero, slen, &hi, &lo );
+				for( int r0 = 0; r0 < n_rank; r0 += 64 ){
+					unsigned long long	W = 0;
+					if( valid && r0 <= hi - lo ){
+						W = ~0ull;
+						const int	w0 = hi - r0 - 63;		// end position of window bit 0
+						for( int h = 0; h < hl0; h++ ){
+							const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector
+							unsigned long long	ph = 0;
+							if( qq >= 0 ){
+								const unsigned long long	*row = pb + rmd_code( sq, szero + h ) * pb_words;
+								const int	wi = qq >> 6, sh = qq & 63;
+								const unsigned long long	a0 = row[ wi ], a1 = row[ wi + 1 ];
+								ph = sh ? ( a0 >> sh ) | ( a1 << ( 64 - sh ) ) : a0;
+							}
+							W &= ph;
+						}
+						const int	imin = lo - w0;			// window bits below lo are not end positions
+						if( imin > 0 )
+							W = imin >= 64 ? 0 : W & ( ~0ull << imin );
+					}
+					while( __ballot( W != 0 ) ){
+						const bool	has = W != 0;
+						const int	i = has ? __ffsll( W ) - 1 : 0;
+						const int	r = r0 + 63 - i;
+						QPUSH( has, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+						W &= W - 1;
+					}
+				}
+			}
+		}else
 		for( int j = 0; j < T; j += BLOCK ){
 			const int	rel = j + tid;
 			const int	szero = z0 + rel;
@@ -165,48 +245,49 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int dbg )
 				rmd_level0_range( P, szero, slen, &hi, &lo );
 			const int	steps = quick ? n_rank : 1;
 			for( int r = 0; r < steps; r++ ){
-				bool	pred;
-				unsigned	item;
 				if( quick ){
 					const int	sd = hi - r;
-					pred = valid && sd >= lo &&
+					const bool	pred = valid && sd >= lo &&
 						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) );
-					item = ( unsigned( rel ) << 16 ) | unsigned( r );
-				}else{
-					pred = valid;
-					item = ( unsigned( rel ) << 16 ) | 0xffffu;
-				}
-				const unsigned long long	m = __ballot( pred );
-				if( m == 0 )
-					continue;
-				int	base = 0;
-				if( lane_id == __ffsll( ( unsigned long long )m ) - 1 )
-					base = atomicAdd( &s_qn, __popcll( m ) );
-				base = __shfl( base, __ffsll( ( unsigned long long )m ) - 1 );
-				if( pred ){
-					const int	slot = base + __popcll( m & lt_mask );
-					if( slot < QCAP )
-						queue[ slot ] = item;
-					else	// queue full: search it right here
-						rmd_search_position( P, &lane, sq, szero, slen, quick ? r : 0,
-							quick ? 1 : RMD_ALL_RANKS, sink );
-				}
+					QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+				}else
+					QPUSH( valid, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
 			}
 		}
+#undef QPUSH
 		__syncthreads();
 
-		// ---- pass B: the full search, one queued item per lane
+		// ---- pass B: the full search.  Lanes are persistent within the tile: a lane
+		// that finishes its item pops the next one at once (wave-aggregated pop), so a
+		// wave lasts as long as its share of the work, not as its slowest item times
+		// the number of rounds.
 		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < QCAP ? s_qn : QCAP );
 		if( ( dbg & 2 ) && tid == 0 )
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
-		for( int i = tid; i < nq; i += BLOCK ){
-			const unsigned	item = queue[ i ];
-			const int	szero = z0 + int( item >> 16 );
-			const int	r = int( item & 0xffffu );
-			if( r == 0xffff )
-				rmd_search_position( P, &lane, sq, szero, slen, 0, RMD_ALL_RANKS, sink );
-			else
-				rmd_search_position( P, &lane, sq, szero, slen, r, 1, sink );
+		int	k = -1;
+		bool	dry = false;
+		for( ; ; ){
+			const unsigned long long	want = __ballot( k < 0 && !dry );
+			if( want ){
+				int	base = 0;
+				if( lane_id == __ffsll( want ) - 1 )
+					base = atomicAdd( &s_qhead, __popcll( want ) );
+				base = __shfl( base, __ffsll( want ) - 1 );
+				if( k < 0 && !dry ){
+					const int	i = base + __popcll( want & lt_mask );
+					if( i < nq ){
+						const unsigned	item = queue[ i ];
+						const int	r = int( item & 0xffffu );
+						k = rmd_search_begin( P, &lane, z0 + int( item >> 16 ), slen,
+							r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+					}else
+						dry = true;
+				}
+			}
+			if( __ballot( k >= 0 ) == 0 )
+				break;
+			if( k >= 0 )
+				k = rmd_search_step( P, &lane, sq, k, sink );
 		}
 		__syncthreads();
 	}
@@ -476,7 +557,8 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	DbView	v = view_of( sc, db );
 	const rmd_program_t	&dp = sc->dprog;
 	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	size_t	lds = PROG_LDS_BYTES + QCAP * sizeof( unsigned ) + size_t( tile_bytes );
+	size_t	pb_bytes = 5 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	size_t	lds = PROG_LDS_BYTES + QCAP * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;
@@ -490,7 +572,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		hipLaunchKernelGGL( rma_search_kernel<BLOCK>, dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-			sc->d_prog, v, hb, getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0 );
+			sc->d_prog, v, hb, tile_bytes, getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0 );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );

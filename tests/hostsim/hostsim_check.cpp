@@ -123,6 +123,10 @@ int main( int argc, char **argv )
 			}
 			fclose( fp );
 		}
+#ifdef RMD_STATS
+		fprintf( stderr, "stats: items %lld, rmd_next calls %lld, inner iterations %lld (ph0 ss %lld, ph0 other %lld), match_wchlx %lld\n",
+			rmd_stat[ 5 ], rmd_stat[ 0 ], rmd_stat[ 1 ], rmd_stat[ 2 ], rmd_stat[ 3 ], rmd_stat[ 4 ] );
+#endif
 		printf( "%s: %lld candidates, %lld mismatching strands\n", args.dfname.c_str(), ( long long )total, ( long long )bad );
 		return bad ? 1 : 0;
 	}catch( rma::Error &e ){
