@@ -49,6 +49,10 @@ bool build_regex( const rma_regex_t &re, rmd_regex_t *out )
 	}
 	out->n_states = n;
 	out->n_close = longest;
+	if( re.anchored ){
+		while( out->n_prefix < n && !( ( out->opt >> out->n_prefix ) & 1 ) )
+			out->n_prefix++;
+	}
 	return true;
 }
 
@@ -224,6 +228,51 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 	}
 	for( int k = 0; k < p->n_efn_sites; k++ )
 		out->efn_sites[ k ] = p->efn_sites[ k ];
+	// Best literal (optimize_query, compile.c:3315-3392; mm_classccnt, mm_regexp.c:232):
+	// the fixed-length seq= with the most "effective characters" whose offset from the
+	// start of the motif is bounded.  Necessary condition only, so output neutral.
+	out->lit_re = -1;
+	{
+		double	best = 0;
+		int	lmin = 0, lmax = 0;		// offset range of element i from the motif start
+		for( int i = 0; i < p->n_elems; i++ ){
+			const rma_elem_t	&e = p->elems[ i ];
+			if( e.re >= 0 && e.mismatch == 0 && lmax != RMA_UNBOUNDED && e.maxlen != RMA_UNBOUNDED ){
+				const rma_regex_t	&re = p->regexes[ e.re ];
+				const rmd_regex_t	&dre = out->regexes[ e.re ];
+				if( re.fixed_len > 0 && dre.opt == 0 && dre.n_states == re.fixed_len ){
+					double	ecnt = 0;
+					for( int a = 0; a < re.n_atoms; a++ ){
+						int	bits = __builtin_popcount( re.atoms[ a ].mask & 0xf );
+						double	c = bits >= 4 ? 0 : bits == 3 ? 0.25 : bits == 2 ? 0.5 : bits == 1 ? 1.0 : 0;
+						if( re.atoms[ a ].mask & 0x10 )
+							c = 0;		// accepts ambiguity letters too: no information
+						ecnt += c * re.atoms[ a ].lo;
+					}
+					int	n = re.fixed_len;
+					int	lo = lmin, hi = lmax;
+					if( re.anchored && re.dollar ){
+						// whole element
+					}else if( re.anchored ){
+						// at the element's first base
+					}else if( re.dollar ){
+						lo = lmin + e.minlen - n;
+						hi = lmax + e.maxlen - n;
+					}else
+						hi = lmax + e.maxlen - n;
+					if( ecnt >= 2.5 && ecnt > best && lo >= 0 && hi >= lo && hi - lo < 4096 ){
+						best = ecnt;
+						out->lit_re = e.re;
+						out->lit_lo = lo;
+						out->lit_hi = hi;
+					}
+				}
+			}
+			lmin += e.minlen;
+			if( lmax != RMA_UNBOUNDED )
+				lmax = e.maxlen == RMA_UNBOUNDED ? RMA_UNBOUNDED : lmax + e.maxlen;
+		}
+	}
 	out->lmargin = 1;
 	out->rmargin = 1;
 	if( p->has_lctx && p->lctx.re >= 0 )

@@ -30,6 +30,7 @@ struct rmd_regex_t {
 	int32_t	n_close;		// longest run of skippable states
 	int32_t	anchored, dollar;
 	int32_t	fixed_len;		// >= 0: every state mandatory (mismatch mode legal)
+	int32_t	n_prefix;		// leading states that cannot be skipped (0 unless anchored)
 };
 
 struct rmd_pairset_t {
@@ -75,6 +76,9 @@ struct rmd_program_t {
 	int32_t	efn_usestdbp, efn_stdbp;
 	int32_t	hit_stride;
 	int32_t	lmargin, rmargin;	// bases needed before szero / after the window
+	// best-literal pre-filter (the role of the reference's -O, compile.c:3315): regex lit_re
+	// must occur with its first base at an offset in [lit_lo, lit_hi] from the start position
+	int32_t	lit_re, lit_lo, lit_hi;
 	int8_t	searches[ RMD_MAX_ELEMS ];
 	rmd_elem_t	elems[ RMD_MAX_ELEMS ];
 	rmd_elem_t	lctx, rctx;

@@ -20,6 +20,11 @@
 #ifndef RMD_FN
 #define RMD_FN	static inline
 #endif
+// rarely taken paths (constraints, multi-strand helices, end-of-list checks): kept
+// out of line in the kernel so the common ss / proper-helix path stays small
+#ifndef RMD_COLD
+#define RMD_COLD	static
+#endif
 
 #define RMD_UNDEF	(-1)
 
@@ -100,7 +105,7 @@ RMD_FN uint64_t rmd_re_close( const rmd_regex_t &re, uint64_t f )
 	return f;
 }
 
-RMD_FN int rmd_re_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len )
+RMD_COLD int rmd_re_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len )
 {
 	uint64_t	act = 0, endbit = 1ull << re.n_states;
 	for( int pos = 0; ; pos++ ){
@@ -120,7 +125,7 @@ RMD_FN int rmd_re_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int
 
 // mm_step()/mm_advance() (mm_regexp.c:353-469): fixed length expressions only.
 // *n_mm is left as the last attempt left it.
-RMD_FN int rmd_re_mm_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len, int l_mm, int *n_mm )
+RMD_COLD int rmd_re_mm_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len, int l_mm, int *n_mm )
 {
 	int	n = re.n_states;
 	for( int st = 0; ; st++ ){
@@ -157,6 +162,21 @@ RMD_FN int rmd_chk_seq( const rmd_program_t *P, const rmd_elem_t &e, const rmd_s
 	if( e.mismatch > 0 )
 		return rmd_re_mm_step( re, sq, off, len, e.mismatch, n_mm );
 	return rmd_re_step( re, sq, off, len );
+}
+
+// Necessary condition for chk_seq( e, s5, len ) with any len >= e.minlen: the
+// leading mandatory positions of an anchored seq= must accept the bases at s5.
+// Used to drop start positions before any search state is touched.
+RMD_FN int rmd_prefix_ok( const rmd_program_t *P, const rmd_elem_t &e, const rmd_seq_t &sq, int s5 )
+{
+	if( e.re < 0 || e.mismatch > 0 )
+		return 1;
+	const rmd_regex_t	&re = P->regexes[ e.re ];
+	int	n = re.n_prefix < e.minlen ? re.n_prefix : e.minlen;
+	for( int i = 0; i < n; i++ )
+		if( !( ( re.accept[ rmd_code( sq, s5 + i ) ] >> i ) & 1 ) )
+			return 0;
+	return 1;
 }
 
 // ---------------------------------------------------------------- helix matchers
@@ -230,7 +250,7 @@ RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq
 }
 
 // match_phlx(), find_motif.c:1114
-RMD_FN int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+RMD_COLD int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
 	int d5, int d3, int s5, int s3, int s5hi, int s5lo, int *hlen, int *n_mpr )
 {
 	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
@@ -286,7 +306,7 @@ RMD_FN int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_
 }
 
 // match_triplex(), find_motif.c:1183
-RMD_FN int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+RMD_COLD int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
 	int d, int d1, int s1, int s2, int s3, int tlen, int *n_mpr )
 {
 	const rmd_elem_t	&stp = P->elems[ d ], &stp1 = P->elems[ d1 ];
@@ -321,7 +341,7 @@ RMD_FN int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd_s
 }
 
 // match_4plex(), find_motif.c:1234
-RMD_FN int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+RMD_COLD int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
 	int d1, int d2, int s1, int s2, int s3, int s4, int qlen, int *n_mpr )
 {
 	const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
@@ -405,7 +425,7 @@ RMD_FN int rmd_wtype( const rmd_program_t *P, const rmd_lane_t *L, int pos, int 
 	return undef_is_ss ? RMA_T_SS : -1;
 }
 
-RMD_FN int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_motif :1406
+RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_motif :1406
 {
 	for( int d = 0; d < P->n_elems; d++ ){
 		const rmd_elem_t	&stp = P->elems[ d ];
@@ -468,7 +488,7 @@ RMD_FN int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const rmd
 	return 1;
 }
 
-RMD_FN int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq )	// set_context :1720
+RMD_COLD int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq )	// set_context :1720
 {
 	if( P->has_lctx ){
 		int	off = L->moff[ 0 ] - P->lctx.maxlen;
@@ -503,7 +523,7 @@ RMD_FN int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq
 	return 1;
 }
 
-RMD_FN int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_sites :1758
+RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_sites :1758
 {
 	for( int s = 0; s < P->n_sites; s++ ){
 		const rmd_site_t	&si = P->sites[ s ];
@@ -613,7 +633,7 @@ RMD_FN void rmd_upd_pksearches( const rmd_program_t *P, rmd_lane_t *L, int d, in
 
 // Advance level k to its next alternative.  Returns 1 with the alternative
 // applied (elements marked, later windows set), 0 when the level is exhausted.
-RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
+RMD_COLD int rmd_next_general( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
 {
 	const int	d = P->searches[ k ];
 	const rmd_elem_t	&stp = P->elems[ d ];
@@ -833,6 +853,14 @@ RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
 						f.ph = 1;
 						continue;
 					}
+					// 3' ends whose first pairs cannot start the helix change nothing: skip them
+					while( f.c >= f.d &&
+						!rmd_quick_wchlx( P, stp, sq, f.e, f.c, rmd_s3lim( f.e, f.c, f.i_minl, stp.maxlen ) ) )
+						f.c--;
+					if( f.c < f.d ){
+						f.ph = 1;
+						continue;
+					}
 					const int	s5 = f.e, s3 = f.c--;
 					f.f = s3;
 					int	s3lim = rmd_s3lim( s5, s3, f.i_minl, stp.maxlen );
@@ -846,6 +874,8 @@ RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
 					continue;
 				}
 				const int	s5 = f.a++;
+				if( !rmd_prefix_ok( P, stp, sq, s5 ) )
+					continue;
 				int	slen3 = sdollar - s5 + 1;
 				int	i_minl = rmd_find_minlen( P, L, d + 1, d3 - 1 );
 				int	g_minl = 2 * stp.minlen + i_minl;
@@ -963,8 +993,101 @@ RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
 	}
 }
 
+// The same generator restricted to the two element kinds almost every level
+// has -- ss (find_ss :332) and a proper Watson-Crick helix (find_wchlx :400) --
+// so that the common path is small enough to stay in registers.  Must agree
+// with rmd_next_general() on these kinds (tests/hostsim checks both).
+RMD_FN int rmd_next_hot( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
+{
+	const int	d = P->searches[ k ];
+	const rmd_elem_t	&stp = P->elems[ d ];
+	rmd_frame_t	&f = L->fr[ k ];
+	const int	is_ss = stp.type == RMA_T_SS;
+	const int	d3 = stp.mates[ 0 ];
+
+	for( ; ; ){
+		if( f.ph != 0 ){
+			const int	szero = L->zero[ k ], sdollar = L->dollar[ k ];
+			rmd_unmark( L, d );
+			if( is_ss ){
+				f.ph = 0;
+				continue;
+			}
+			rmd_unmark( L, d3 );
+			if( f.cand == 0 ){
+				f.ph = 0;
+				continue;
+			}
+			const int	hl = rmd_ctz64( f.cand );
+			f.cand &= f.cand - 1;
+			if( sdollar - szero - 2 * hl + 1 > stp.maxilen )
+				continue;
+			const int	mpr = rmd_popc64( f.mis & ( ( 1ull << hl ) - 1 ) );
+			L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
+			rmd_mark( L, d, szero, hl );
+			rmd_mark( L, d3, sdollar - hl + 1, hl );
+			L->zero[ stp.inner_s ] = szero + hl;
+			L->dollar[ stp.inner_s ] = sdollar - hl;
+			return 1;
+		}
+		if( stp.quick ){
+			const int	z = L->zero[ k ];
+			while( f.sd >= f.sd_lo &&
+				!rmd_quick_wchlx( P, stp, sq, z, f.sd, rmd_s3lim( z, f.sd, stp.q_iminl, stp.maxlen ) ) )
+				f.sd--;
+		}
+		if( f.sd < f.sd_lo ){
+			L->dollar[ k ] = f.o_sd;
+			return 0;
+		}
+		if( stp.loop ){
+			if( k == 0 ){
+				L->rank = L->hi0 - f.sd;
+				L->order = 0;
+			}
+			L->dollar[ k ] = f.sd;
+			if( stp.next_s >= 0 ){
+				L->zero[ stp.next_s ] = f.sd + 1;
+				L->dollar[ stp.next_s ] = f.o_sd;
+			}
+		}
+		f.sd--;
+		const int	szero = L->zero[ k ], sdollar = L->dollar[ k ], slen = sdollar - szero + 1;
+		if( is_ss ){
+			L->mm[ d ] = 0;
+			L->mpr[ d ] = 0;
+			if( slen < stp.minlen || slen > stp.maxlen )
+				continue;
+			if( stp.re >= 0 ){
+				int	mm = 0;
+				int	ok = rmd_chk_seq( P, stp, sq, szero, slen, &mm );
+				L->mm[ d ] = int16_t( mm );
+				if( !ok )
+					continue;
+			}
+			rmd_mark( L, d, szero, slen );
+			f.ph = 1;
+			return 1;
+		}
+		L->mm[ d ] = L->mpr[ d ] = 0;
+		L->mm[ d3 ] = L->mpr[ d3 ] = 0;
+		if( rmd_match_wchlx( P, L, sq, d, d3, szero, sdollar, rmd_s3lim( szero, sdollar, stp.minilen, stp.maxlen ), &f.cand, &f.mis ) )
+			f.ph = 1;
+	}
+}
+
+RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
+{
+	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
+#ifndef RMD_NO_HOT_PATH
+	if( stp.type == RMA_T_SS || ( stp.type == RMA_T_H5 && stp.proper ) )
+		return rmd_next_hot( P, L, sq, k );
+#endif
+	return rmd_next_general( P, L, sq, k );
+}
+
 // Write one candidate (find_ss :373-392 up to the RM_score() call).
-RMD_FN void rmd_fill_hit( const rmd_program_t *P, const rmd_lane_t *L, int seq, int comp, int szero, int32_t *w )
+RMD_COLD void rmd_fill_hit( const rmd_program_t *P, const rmd_lane_t *L, int seq, int comp, int szero, int32_t *w )
 {
 	w[ 0 ] = seq;
 	w[ 1 ] = comp;

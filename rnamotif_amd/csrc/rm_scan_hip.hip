@@ -24,6 +24,7 @@
 #include <vector>
 
 #define RMD_FN		static __device__ inline
+#define RMD_COLD	static __device__ inline
 #define RMD_FN_MEMBER	__device__ inline
 #include "rm_scan_core.h"
 #include "rm_efn_core.h"
@@ -74,11 +75,16 @@ struct DevSink {
 };
 
 #define PROG_LDS_BYTES	( ( sizeof( rmd_program_t ) + 15 ) & ~size_t( 15 ) )
-#define QCAP		8192		// work queue entries per workgroup
+#ifndef QCAP
+#define QCAP		2048		// work queue entries per workgroup
+#endif
 
 // ---------------------------------------------------------------- search kernel
+#ifndef SEARCH_WAVES_PER_SIMD
+#define SEARCH_WAVES_PER_SIMD	5
+#endif
 template< int BLOCK >
-__global__ void __launch_bounds__( BLOCK )
+__global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
 rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
@@ -109,9 +115,15 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 	const bool	bitpar = quick && !( dbg & 4 ) && e0.mplim == 0 && !e0.pfrac && ( e0.ends & RMA_5PAIRED ) &&
 		e0.minlen >= 1;
 	const unsigned	e0_mat2 = quick ? P->pairsets[ e0.pairset ].mat2 : 0;
+	const bool	e0_at_szero = e0.type == RMA_T_P5 || e0.type == RMA_T_T1 || e0.type == RMA_T_Q1 ||
+		( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
 	const int	pb_words = ( tile_bytes + 63 ) / 64 + 3;
 	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + PROG_LDS_BYTES + QCAP * sizeof( unsigned ) +
 		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
+	unsigned long long	*occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
+	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
+	const int	lit_n = lit ? P->regexes[ P->lit_re ].n_states : 0;
+	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
 
 	for( ; ; ){
 		if( tid == 0 ){
@@ -165,6 +177,38 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		DevSink	sink{ hb, seq, comp, P->hit_stride };
 		const int	lane_id = tid & 63;
 		const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
+		// Best-literal filter (the reference's -O skip scan, find_motif.c:209-243, as a
+		// necessary condition): occ has a bit for every tile position where the literal
+		// starts; a start position is searched only if one lies at an allowed offset.
+		if( lit ){
+			const rmd_regex_t	&lre = P->regexes[ P->lit_re ];
+			const int	n_valid = p_to - p_lo;
+			for( int base = ( tid >> 6 ) * 64; base < pb_words * 64; base += BLOCK ){
+				const int	q = base + lane_id - 64;
+				bool	ok = q >= p_from - p_lo && q + lit_n <= n_valid;
+				for( int jj = 0; ok && jj < lit_n; jj++ )
+					ok = ( lre.accept[ tile[ q + jj ] ] >> jj ) & 1;
+				const unsigned long long	m = __ballot( ok );
+				if( lane_id == 0 )
+					occ[ base >> 6 ] = m;
+			}
+			__syncthreads();
+		}
+#define LIT_OK( szero_, res_ )	do{ \
+		res_ = true; \
+		if( lit ){ \
+			res_ = false; \
+			const int	b1_ = ( szero_ ) + lit_hi - p_lo + 64; \
+			for( int b0_ = ( szero_ ) + P->lit_lo - p_lo + 64; b0_ <= b1_ && !res_; b0_ += 64 ){ \
+				const int	wi_ = b0_ >> 6, sh_ = b0_ & 63; \
+				unsigned long long	x_ = sh_ ? ( occ[ wi_ ] >> sh_ ) | ( occ[ wi_ + 1 ] << ( 64 - sh_ ) ) : occ[ wi_ ]; \
+				const int	nb_ = b1_ - b0_ + 1; \
+				if( nb_ < 64 ) \
+					x_ &= ( 1ull << nb_ ) - 1; \
+				res_ = x_ != 0; \
+			} \
+		} }while( 0 )
+
 		// push( pred, item ): one ballot + prefix count per call; overflow is searched in place
 #define QPUSH( pred, item, szero_, r0_, cnt_ )	do{ \
 		const unsigned long long	m_ = __ballot( pred ); \
@@ -202,7 +246,9 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			for( int j = 0; j < T; j += BLOCK ){
 				const int	rel = j + tid;
 				const int	szero = z0 + rel;
-				const bool	valid = rel < T && szero <= slen - P->dminlen;
+				bool	valid = rel < T && szero <= slen - P->dminlen;
+				if( valid )
+					LIT_OK( szero, valid );
 				int	hi = 0, lo = 1;
 				if( valid )
 					rmd_level0_range( P, szero, slen, &hi, &lo );
@@ -239,7 +285,9 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		for( int j = 0; j < T; j += BLOCK ){
 			const int	rel = j + tid;
 			const int	szero = z0 + rel;
-			const bool	valid = rel < T && szero <= slen - P->dminlen;
+			bool	valid = rel < T && szero <= slen - P->dminlen;
+			if( valid )
+				LIT_OK( szero, valid );
 			int	hi = 0, lo = 1;
 			if( valid && quick )
 				rmd_level0_range( P, szero, slen, &hi, &lo );
@@ -250,11 +298,16 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 					const bool	pred = valid && sd >= lo &&
 						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) );
 					QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
-				}else
-					QPUSH( valid, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
+				}else{
+					// helices whose 5' strand starts at the start position: its anchored
+					// seq= prefix must be there
+					const bool	pred = valid && ( !e0_at_szero || rmd_prefix_ok( P, e0, sq, szero ) );
+					QPUSH( pred, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
+				}
 			}
 		}
 #undef QPUSH
+#undef LIT_OK
 		__syncthreads();
 
 		// ---- pass B: the full search.  Lanes are persistent within the tile: a lane
@@ -339,7 +392,7 @@ struct rma_scanner {
 	int64_t	hit_cap = 0;
 	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
 	std::vector<int32_t>	h_raw, h_sorted;
-	int	tile_t = 2048;
+	int	tile_t = 4096;
 	int	grid_blocks = 0;
 };
 
@@ -557,7 +610,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	DbView	v = view_of( sc, db );
 	const rmd_program_t	&dp = sc->dprog;
 	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	size_t	pb_bytes = 5 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = PROG_LDS_BYTES + QCAP * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );

@@ -50,7 +50,27 @@ static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int sl
 	if( e0.type == RMA_T_Q1 )
 		i_minl0 += dp->elems[ e0.mates[ 0 ] ].minilen + dp->elems[ e0.mates[ 1 ] ].minilen + 2 * e0.minlen;
 	for( int szero = 0; szero <= slen - dp->dminlen; szero++ ){
+		if( dp->lit_re >= 0 && !getenv( "HOSTSIM_NOQUICK" ) ){
+			// best-literal filter, as in the kernel
+			const rmd_regex_t	&lre = dp->regexes[ dp->lit_re ];
+			int	n = lre.n_states, hi = std::min( dp->lit_hi, dp->w_winsize - n );
+			bool	found = false;
+			for( int q = szero + dp->lit_lo; q <= szero + hi && !found; q++ ){
+				if( q + n > slen )
+					break;
+				bool	ok = true;
+				for( int j = 0; ok && j < n; j++ )
+					ok = ( lre.accept[ codes[ q + j ] ] >> j ) & 1;
+				found = ok;
+			}
+			if( !found )
+				continue;
+		}
 		if( !quick || getenv( "HOSTSIM_NOQUICK" ) ){
+			bool	at_szero = e0.type == RMA_T_P5 || e0.type == RMA_T_T1 || e0.type == RMA_T_Q1 ||
+				( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
+			if( !getenv( "HOSTSIM_NOQUICK" ) && at_szero && !rmd_prefix_ok( dp, e0, sq, szero ) )
+				continue;
 			rmd_search_position( dp, &lane, sq, szero, slen, 0, RMD_ALL_RANKS, sink );
 			continue;
 		}
