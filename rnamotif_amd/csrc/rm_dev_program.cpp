@@ -139,8 +139,16 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		d->q_iminl = e.minilen;
 		if( e.type == RMA_T_Q1 )
 			d->q_iminl += p->elems[ e.mates[ 0 ] ].minilen + p->elems[ e.mates[ 1 ] ].minilen + 2 * e.minlen;
-		if( e.type == RMA_T_H5 && !e.proper )
+		if( e.type == RMA_T_H5 && !e.proper ){
 			out->need_init = 1;
+			// find_pknot3 :558-562 with nothing matched yet: plain sums of minlen
+			d->q_iminl = 0;
+			for( int k = e.index + 1; k < e.mates[ 0 ]; k++ )
+				d->q_iminl += p->elems[ k ].minlen;
+			d->q_sminl = 0;
+			for( int k = e.mates[ 0 ] + 1; k <= e.scopes[ e.n_scopes - 1 ]; k++ )
+				d->q_sminl += p->elems[ k ].minlen;
+		}
 		// every strand of a helix carries the group's rules (match_4plex reads them from q2)
 		bool	helix = e.type != RMA_T_SS && e.type != RMA_T_CTX;
 		if( helix ){

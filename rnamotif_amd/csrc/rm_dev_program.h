@@ -53,6 +53,7 @@ struct rmd_elem_t {
 	int8_t	pfrac;			// pairfrac rule active
 	int8_t	quick;			// level searched with match_wchlx at (zero, sdollar): proper h5, q1
 	int32_t	q_iminl;		// interior minimum of that match (find_motif.c:423,884)
+	int32_t	q_sminl;		// first pseudoknot helix: least length after its 3' strand (:561)
 	int32_t	minlen, maxlen, minglen, maxglen, minilen, maxilen;
 	int32_t	mismatch;
 	int32_t	mplim;			// match_wchlx/match_phlx mispair limit

@@ -112,9 +112,11 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 	const bool	quick = ( ( e0.type == RMA_T_H5 && e0.proper ) || e0.type == RMA_T_Q1 ) && n_rank < 0xffff;
 	// helices that allow no mispair at all (find_motif.c:1010-1033 with mplim == 0) take
 	// the bit-parallel pre-filter
-	const bool	bitpar = quick && !( dbg & 4 ) && e0.mplim == 0 && !e0.pfrac && ( e0.ends & RMA_5PAIRED ) &&
-		e0.minlen >= 1;
-	const unsigned	e0_mat2 = quick ? P->pairsets[ e0.pairset ].mat2 : 0;
+	// first helix of a pseudoknot whose 5' strand starts at the start position
+	const bool	pk0 = e0.type == RMA_T_H5 && !e0.proper && e0.scope == 0 && !( dbg & 4 ) &&
+		e0.mplim <= 3 && e0.minlen >= 1;
+	const bool	bitpar = ( ( quick && !( dbg & 4 ) ) || pk0 ) && e0.mplim <= 3 && e0.minlen >= 1;
+	const unsigned	e0_mat2 = e0.pairset >= 0 ? P->pairsets[ e0.pairset ].mat2 : 0;
 	const bool	e0_at_szero = e0.type == RMA_T_P5 || e0.type == RMA_T_T1 || e0.type == RMA_T_Q1 ||
 		( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
 	const int	pb_words = ( tile_bytes + 63 ) / 64 + 3;
@@ -124,6 +126,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
 	const int	lit_n = lit ? P->regexes[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
+	const bool	split_ranks = !quick && lit && n_rank > 1 && n_rank < 0xffff;
 
 	for( ; ; ){
 		if( tid == 0 ){
@@ -243,6 +246,40 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			}
 			__syncthreads();
 			const int	hl0 = e0.minlen;
+			// superset of match_wchlx's rule (find_motif.c:1010-1033,1065-1080): at most mplim
+			// mispairs among the first minlen pairs; an unpaired first pair is allowed only if
+			// the 5' end may be unpaired (then it is the one mispair that is always tolerated)
+			const int	lim = ( e0.ends & RMA_5PAIRED ) ? e0.mplim : ( e0.mplim > 1 ? e0.mplim : 1 );
+			// end positions top-r0-63 .. top-r0 of a helix starting at szero: bit i set when
+			// end position top-r0-63+i passes; positions below lo are cleared
+			auto	win = [ & ]( int szero, int top, int r0, int lo ) -> unsigned long long {
+				unsigned long long	c1 = 0, c2 = 0, c3 = 0, c4 = 0, first = 0;	// >= 1/2/3/4 mispairs
+				const int	w0 = top - r0 - 63;
+				for( int h = 0; h < hl0; h++ ){
+					const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector
+					unsigned long long	ph = 0;
+					if( qq >= 0 ){
+						const unsigned long long	*row = pb + rmd_code( sq, szero + h ) * pb_words;
+						const int	wi = qq >> 6, sh = qq & 63;
+						const unsigned long long	a0 = row[ wi ], a1 = row[ wi + 1 ];
+						ph = sh ? ( a0 >> sh ) | ( a1 << ( 64 - sh ) ) : a0;
+					}
+					const unsigned long long	mis = ~ph;
+					if( h == 0 )
+						first = mis;
+					c4 |= c3 & mis;
+					c3 |= c2 & mis;
+					c2 |= c1 & mis;
+					c1 |= mis;
+				}
+				unsigned long long	W = ~( lim == 0 ? c1 : lim == 1 ? c2 : lim == 2 ? c3 : c4 );
+				if( e0.ends & RMA_5PAIRED )
+					W &= ~first;
+				const int	imin = lo - w0;
+				if( imin > 0 )
+					W = imin >= 64 ? 0 : W & ( ~0ull << imin );
+				return W;
+			};
 			for( int j = 0; j < T; j += BLOCK ){
 				const int	rel = j + tid;
 				const int	szero = z0 + rel;
@@ -252,26 +289,28 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 				int	hi = 0, lo = 1;
 				if( valid )
 					rmd_level0_range( P, szero, slen, &hi, &lo );
+				if( pk0 ){
+					// first helix of a pseudoknot (find_pknot5/find_pknot3 :495-640): its 3' end
+					// lies between s5 + 2*minlen + interior - 1 and the window end minus what must
+					// follow it; search the position only if some end there can start the helix
+					bool	any = false;
+					if( valid ){
+						const int	top = hi - e0.q_sminl, bot = szero + 2 * e0.minlen + e0.q_iminl - 1;
+						for( int r0 = 0; !any && r0 <= top - bot; r0 += 64 )
+							any = win( szero, top, r0, bot ) != 0;
+						any = any && rmd_prefix_ok( P, e0, sq, szero );
+					}
+					if( split_ranks ){
+						for( int r = 0; r < n_rank; r++ )
+							QPUSH( any && r <= hi - lo, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+					}else
+						QPUSH( any, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
+					continue;
+				}
 				for( int r0 = 0; r0 < n_rank; r0 += 64 ){
 					unsigned long long	W = 0;
-					if( valid && r0 <= hi - lo ){
-						W = ~0ull;
-						const int	w0 = hi - r0 - 63;		// end position of window bit 0
-						for( int h = 0; h < hl0; h++ ){
-							const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector
-							unsigned long long	ph = 0;
-							if( qq >= 0 ){
-								const unsigned long long	*row = pb + rmd_code( sq, szero + h ) * pb_words;
-								const int	wi = qq >> 6, sh = qq & 63;
-								const unsigned long long	a0 = row[ wi ], a1 = row[ wi + 1 ];
-								ph = sh ? ( a0 >> sh ) | ( a1 << ( 64 - sh ) ) : a0;
-							}
-							W &= ph;
-						}
-						const int	imin = lo - w0;			// window bits below lo are not end positions
-						if( imin > 0 )
-							W = imin >= 64 ? 0 : W & ( ~0ull << imin );
-					}
+					if( valid && r0 <= hi - lo )
+						W = win( szero, hi, r0, lo );
 					while( __ballot( W != 0 ) ){
 						const bool	has = W != 0;
 						const int	i = has ? __ffsll( W ) - 1 : 0;
@@ -291,9 +330,18 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			int	hi = 0, lo = 1;
 			if( valid && quick )
 				rmd_level0_range( P, szero, slen, &hi, &lo );
-			const int	steps = quick ? n_rank : 1;
+			if( valid && split_ranks )
+				rmd_level0_range( P, szero, slen, &hi, &lo );
+			const int	steps = ( quick || split_ranks ) ? n_rank : 1;
 			for( int r = 0; r < steps; r++ ){
-				if( quick ){
+				if( split_ranks ){
+					// few start positions survive the filters: hand their end positions
+					// out one by one so that the lanes of pass B all get work
+					const bool	pred = valid && r <= hi - lo && ( r > 0 || !e0_at_szero || rmd_prefix_ok( P, e0, sq, szero ) );
+					if( r == 0 && valid && !pred )
+						valid = false;
+					QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+				}else if( quick ){
 					const int	sd = hi - r;
 					const bool	pred = valid && sd >= lo &&
 						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) );
