@@ -109,6 +109,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		if( !build_regex( p->regexes[ i ], &out->regexes[ i ] ) )
 			FAIL( "a seq= expression expands to more than 63 positions" );
 
+	int	n_rules = 0;
 	auto cvt = [&]( const rma_elem_t &e, rmd_elem_t *d ) -> int {
 		d->type = int8_t( e.type );
 		d->proper = int8_t( e.proper );
@@ -165,6 +166,9 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 				d->mplim = 0;
 				d->pfrac = 0;
 			}
+			// one rule table per distinct (mispair, pairfrac) pair
+			rmd_rule_t	rule;
+			memset( &rule, 0, sizeof( rule ) );
 			for( int hl = 0; hl <= RMD_MAX_HLEN; hl++ ){
 				int	best = 0;
 				if( hl == 0 )
@@ -173,19 +177,32 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 					if( !( 1. * ( hl - mpr ) / hl < e.pairfrac - EPS ) )	// :1040,:1086
 						best = mpr;
 				}
-				d->pf_maxmpr[ hl ] = uint8_t( best );
+				rule.pf_maxmpr[ hl ] = uint8_t( best );
 				int	tq = 0;		// :1190-1194, :1241-1245
 				if( e.mispair > 0 )
 					tq = e.mispair;
 				else if( e.pairfrac < 1.0 )
 					tq = int( ( 1. - e.pairfrac ) * hl + 0.5 );
-				d->tq_mplim[ hl ] = uint8_t( std::min( tq, 255 ) );
+				rule.tq_mplim[ hl ] = uint8_t( std::min( tq, 255 ) );
 			}
+			int	k;
+			for( k = 0; k < n_rules; k++ )
+				if( !memcmp( &out->rules[ k ], &rule, sizeof( rule ) ) )
+					break;
+			if( k == n_rules ){
+				if( n_rules == RMD_MAX_RULES )
+					return 2;
+				out->rules[ n_rules++ ] = rule;
+			}
+			d->rule = k;
 		}
 		return 0;
 	};
 	for( int i = 0; i < p->n_elems; i++ ){
-		if( cvt( p->elems[ i ], &out->elems[ i ] ) )
+		int	rc = cvt( p->elems[ i ], &out->elems[ i ] );
+		if( rc == 2 )
+			FAIL( "more than %d distinct helix mispair/pairfrac rules", RMD_MAX_RULES );
+		if( rc )
 			FAIL( "helix element %d allows %d base pairs; the device scanner takes at most %d",
 				i + 1, p->elems[ i ].maxlen, RMD_MAX_HLEN );
 	}
@@ -223,6 +240,12 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		default :
 			FAIL( "element %d cannot head a search", e.index + 1 );
 		}
+	}
+	out->lean_ok = p->n_searches <= RMD_LEAN_LEVELS && out->w_winsize < 30000;
+	for( int s = 0; s < p->n_searches; s++ ){
+		const rma_elem_t	&e = p->elems[ p->searches[ s ] ];
+		if( !( e.type == RMA_T_SS || ( e.type == RMA_T_H5 && e.proper ) ) )
+			out->lean_ok = 0;
 	}
 	for( int s = 0; s < p->n_sites; s++ ){
 		rmd_site_t	*d = &out->sites[ s ];

@@ -14,9 +14,11 @@
 #ifndef RMD_MAX_ELEMS
 #define RMD_MAX_ELEMS	32	// elements (and search levels) per descriptor on the device
 #endif
+#define RMD_LEAN_LEVELS	16	// most search levels the lean path takes
 #define RMD_MAX_HLEN	63	// longest helix strand: candidate sets are 64-bit masks
-#define RMD_MAX_RE	34
-#define RMD_MAX_PS	40
+#define RMD_MAX_RE	20
+#define RMD_MAX_PS	20
+#define RMD_MAX_RULES	16	// helix groups with their own mispair / pairfrac rule tables
 #define RMD_MAX_SITES	8
 #define RMD_MAX_EFN	8
 
@@ -57,6 +59,11 @@ struct rmd_elem_t {
 	int32_t	minlen, maxlen, minglen, maxglen, minilen, maxilen;
 	int32_t	mismatch;
 	int32_t	mplim;			// match_wchlx/match_phlx mispair limit
+	int32_t	rule;			// index into rules[] (helix strands), else 0
+};
+
+// length dependent helix rules, shared by the strands of one helix
+struct rmd_rule_t {
 	uint8_t	pf_maxmpr[ RMD_MAX_HLEN + 1 ];	// pairfrac test: most mispairs allowed at length hl
 	uint8_t	tq_mplim[ RMD_MAX_HLEN + 1 ];	// match_triplex/match_4plex limit at length tlen
 };
@@ -72,6 +79,7 @@ struct rmd_program_t {
 	int32_t	dminlen, w_winsize;	// min( dmaxlen, windowsize )
 	int32_t	strict_helices;
 	int32_t	need_init;		// some helix is improper: element state must start UNDEF
+	int32_t	lean_ok;		// every level is ss or a proper helix: 8-byte-per-level search
 	int32_t	has_lctx, has_rctx;
 	int32_t	n_sites, n_efn;
 	int32_t	efn_usestdbp, efn_stdbp;
@@ -84,6 +92,7 @@ struct rmd_program_t {
 	rmd_elem_t	elems[ RMD_MAX_ELEMS ];
 	rmd_elem_t	lctx, rctx;
 	rmd_site_t	sites[ RMD_MAX_SITES ];
+	rmd_rule_t	rules[ RMD_MAX_RULES ];
 	rmd_pairset_t	pairsets[ RMD_MAX_PS ];
 	rmd_regex_t	regexes[ RMD_MAX_RE ];
 	rma_efn_site_t	efn_sites[ RMD_MAX_EFN ];

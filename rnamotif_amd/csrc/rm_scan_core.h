@@ -182,13 +182,14 @@ RMD_FN int rmd_prefix_ok( const rmd_program_t *P, const rmd_elem_t &e, const rmd
 // ---------------------------------------------------------------- helix matchers
 // match_wchlx(), find_motif.c:975.  Every candidate ends at s3, so the result
 // is the set of accepted lengths (bit hl of *cand) and the mispair positions.
-RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis )
+// mm5/mm3: s_n_mismatches of the two strands, in (current value) and out.
+RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const rmd_seq_t &sq,
+	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis, int *pmm5, int *pmm3 )
 {
 	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
 	RMD_COUNT( 4 );
 	uint64_t	c = 0, m = 0;
-	int	hl, mpr, l_bpr, mm5 = L->mm[ d5 ], mm3 = L->mm[ d3 ];
+	int	hl, mpr, l_bpr, mm5 = *pmm5, mm3 = *pmm3;
 
 	if( stp.minlen == 0 ){
 		int	ok = 1;
@@ -207,8 +208,8 @@ RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq
 		l_bpr = 0;
 		m |= 1;
 	}else{
-		L->mm[ d5 ] = int16_t( mm5 );
-		L->mm[ d3 ] = int16_t( mm3 );
+		*pmm5 = mm5;
+		*pmm3 = mm3;
 		*cand = c;
 		*mis = m;
 		return c != 0;
@@ -218,7 +219,7 @@ RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq
 			int	ok = 1;
 			if( !l_bpr && ( stp.ends & RMA_3PAIRED ) )
 				ok = 0;
-			else if( stp.pfrac && mpr > stp.pf_maxmpr[ hl ] )
+			else if( stp.pfrac && mpr > P->rules[ stp.rule ].pf_maxmpr[ hl ] )
 				ok = 0;
 			else if( stp.re >= 0 && !rmd_chk_seq( P, stp, sq, s5, hl, &mm5 ) )
 				ok = 0;
@@ -242,11 +243,21 @@ RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq
 		}
 		hl++;
 	}
-	L->mm[ d5 ] = int16_t( mm5 );
-	L->mm[ d3 ] = int16_t( mm3 );
+	*pmm5 = mm5;
+	*pmm3 = mm3;
 	*cand = c;
 	*mis = m;
 	return c != 0;
+}
+
+RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
+	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis )
+{
+	int	mm5 = L->mm[ d5 ], mm3 = L->mm[ d3 ];
+	int	rv = rmd_match_wchlx_mm( P, sq, d5, d3, s5, s3, s3lim, cand, mis, &mm5, &mm3 );
+	L->mm[ d5 ] = int16_t( mm5 );
+	L->mm[ d3 ] = int16_t( mm3 );
+	return rv;
 }
 
 // match_phlx(), find_motif.c:1114
@@ -281,7 +292,7 @@ RMD_COLD int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_se
 			return 0;
 		if( hl < stp.minlen || hl > stp.maxlen )
 			return 0;
-		if( stp.pfrac && mpr > stp.pf_maxmpr[ hl ] )
+		if( stp.pfrac && mpr > P->rules[ stp.rule ].pf_maxmpr[ hl ] )
 			return 0;
 		int	mm;
 		if( stp.re >= 0 ){
@@ -310,7 +321,7 @@ RMD_COLD int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd
 	int d, int d1, int s1, int s2, int s3, int tlen, int *n_mpr )
 {
 	const rmd_elem_t	&stp = P->elems[ d ], &stp1 = P->elems[ d1 ];
-	int	mplim = stp.tq_mplim[ tlen ], mpr, l_pr;
+	int	mplim = P->rules[ stp.rule ].tq_mplim[ tlen ], mpr, l_pr;
 	if( rmd_triple( P, stp.pairset, rmd_code( sq, s1 ), rmd_code( sq, s2 ), rmd_code( sq, s3 - tlen + 1 ) ) ){
 		mpr = 0;
 		l_pr = 1;
@@ -345,7 +356,7 @@ RMD_COLD int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_s
 	int d1, int d2, int s1, int s2, int s3, int s4, int qlen, int *n_mpr )
 {
 	const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
-	int	mplim = stp1.tq_mplim[ qlen ], mpr, l_pr;
+	int	mplim = P->rules[ stp1.rule ].tq_mplim[ qlen ], mpr, l_pr;
 	if( rmd_quad( P, stp1.pairset, rmd_code( sq, s1 + qlen - 1 ), rmd_code( sq, s2 ), rmd_code( sq, s3 ), rmd_code( sq, s4 - qlen + 1 ) ) )
 		l_pr = 1;
 	else if( !( stp1.ends & RMA_5PAIRED ) )
@@ -398,7 +409,7 @@ RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const
 		l_bpr = 0;
 	}
 	for( ; ; ){
-		if( hl >= stp.minlen && ( l_bpr || !( stp.ends & RMA_3PAIRED ) ) && ( !stp.pfrac || mpr <= stp.pf_maxmpr[ hl ] ) )
+		if( hl >= stp.minlen && ( l_bpr || !( stp.ends & RMA_3PAIRED ) ) && ( !stp.pfrac || mpr <= P->rules[ stp.rule ].pf_maxmpr[ hl ] ) )
 			return 1;
 		if( !( s3 - hl + 1 >= s3lim ) || hl >= stp.maxlen )
 			return 0;
@@ -993,96 +1004,8 @@ RMD_COLD int rmd_next_general( const rmd_program_t *P, rmd_lane_t *L, const rmd_
 	}
 }
 
-// The same generator restricted to the two element kinds almost every level
-// has -- ss (find_ss :332) and a proper Watson-Crick helix (find_wchlx :400) --
-// so that the common path is small enough to stay in registers.  Must agree
-// with rmd_next_general() on these kinds (tests/hostsim checks both).
-RMD_FN int rmd_next_hot( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
-{
-	const int	d = P->searches[ k ];
-	const rmd_elem_t	&stp = P->elems[ d ];
-	rmd_frame_t	&f = L->fr[ k ];
-	const int	is_ss = stp.type == RMA_T_SS;
-	const int	d3 = stp.mates[ 0 ];
-
-	for( ; ; ){
-		if( f.ph != 0 ){
-			const int	szero = L->zero[ k ], sdollar = L->dollar[ k ];
-			rmd_unmark( L, d );
-			if( is_ss ){
-				f.ph = 0;
-				continue;
-			}
-			rmd_unmark( L, d3 );
-			if( f.cand == 0 ){
-				f.ph = 0;
-				continue;
-			}
-			const int	hl = rmd_ctz64( f.cand );
-			f.cand &= f.cand - 1;
-			if( sdollar - szero - 2 * hl + 1 > stp.maxilen )
-				continue;
-			const int	mpr = rmd_popc64( f.mis & ( ( 1ull << hl ) - 1 ) );
-			L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
-			rmd_mark( L, d, szero, hl );
-			rmd_mark( L, d3, sdollar - hl + 1, hl );
-			L->zero[ stp.inner_s ] = szero + hl;
-			L->dollar[ stp.inner_s ] = sdollar - hl;
-			return 1;
-		}
-		if( stp.quick ){
-			const int	z = L->zero[ k ];
-			while( f.sd >= f.sd_lo &&
-				!rmd_quick_wchlx( P, stp, sq, z, f.sd, rmd_s3lim( z, f.sd, stp.q_iminl, stp.maxlen ) ) )
-				f.sd--;
-		}
-		if( f.sd < f.sd_lo ){
-			L->dollar[ k ] = f.o_sd;
-			return 0;
-		}
-		if( stp.loop ){
-			if( k == 0 ){
-				L->rank = L->hi0 - f.sd;
-				L->order = 0;
-			}
-			L->dollar[ k ] = f.sd;
-			if( stp.next_s >= 0 ){
-				L->zero[ stp.next_s ] = f.sd + 1;
-				L->dollar[ stp.next_s ] = f.o_sd;
-			}
-		}
-		f.sd--;
-		const int	szero = L->zero[ k ], sdollar = L->dollar[ k ], slen = sdollar - szero + 1;
-		if( is_ss ){
-			L->mm[ d ] = 0;
-			L->mpr[ d ] = 0;
-			if( slen < stp.minlen || slen > stp.maxlen )
-				continue;
-			if( stp.re >= 0 ){
-				int	mm = 0;
-				int	ok = rmd_chk_seq( P, stp, sq, szero, slen, &mm );
-				L->mm[ d ] = int16_t( mm );
-				if( !ok )
-					continue;
-			}
-			rmd_mark( L, d, szero, slen );
-			f.ph = 1;
-			return 1;
-		}
-		L->mm[ d ] = L->mpr[ d ] = 0;
-		L->mm[ d3 ] = L->mpr[ d3 ] = 0;
-		if( rmd_match_wchlx( P, L, sq, d, d3, szero, sdollar, rmd_s3lim( szero, sdollar, stp.minilen, stp.maxlen ), &f.cand, &f.mis ) )
-			f.ph = 1;
-	}
-}
-
 RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
 {
-	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
-#ifndef RMD_NO_HOT_PATH
-	if( stp.type == RMA_T_SS || ( stp.type == RMA_T_H5 && stp.proper ) )
-		return rmd_next_hot( P, L, sq, k );
-#endif
 	return rmd_next_general( P, L, sq, k );
 }
 
@@ -1192,4 +1115,214 @@ RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rm
 	int	k = rmd_search_begin( P, L, szero, slen, r0, cnt );
 	while( k >= 0 )
 		k = rmd_search_step( P, L, sq, k, sink );
+}
+
+// ---------------------------------------------------------------- lean path
+// Descriptors whose search levels are all ss elements and proper Watson-Crick
+// helices (the common case: hairpins, cloverleaves, ...) do not need the general
+// frames.  Per level the whole iterator is 8 bytes -- window start, saved window
+// end, next end position to try, chosen helix length, phase -- kept in LDS; helix
+// candidate sets are recomputed when a level is resumed and the full element
+// table is rebuilt only when a candidate reaches the end of the search list.  The
+// transitions are the ss / proper-helix cases of rmd_next_general() (find_ss :332,
+// find_wchlx :400, find_motif :245); tests/hostsim runs both against the oracle.
+struct alignas( 8 ) rmd_lrec_t {
+	int16_t	zero;		// window start, relative to the item's start position
+	int16_t	osd;		// window end on entry (o_sdollar), relative
+	int16_t	sd;		// next end position to try, relative
+	uint8_t	hl;		// helix length of the current alternative
+	uint8_t	ph;		// 0: looking for an end position, 1: alternative applied
+};
+
+struct rmd_lean_t {
+	int32_t	szero, slen;
+	int32_t	hi0, lo0;	// first level: end position of rank 0, lowest end position allowed
+	int32_t	rank, order;
+};
+
+RMD_FN rmd_lrec_t rmd_lean_open( const rmd_program_t *P, int level, int zero, int osd )	// rmd_enter()
+{
+	const rmd_elem_t	&stp = P->elems[ P->searches[ level ] ];
+	rmd_lrec_t	r;
+	int	hi = osd;
+	if( stp.loop && stp.maxglen != RMA_UNBOUNDED && zero + stp.maxglen - 1 < hi )
+		hi = zero + stp.maxglen - 1;
+	r.zero = int16_t( zero );
+	r.osd = int16_t( osd );
+	r.sd = int16_t( hi );
+	r.hl = 0;
+	r.ph = 0;
+	return r;
+}
+
+template< class LR >
+RMD_FN int rmd_lean_begin( const rmd_program_t *P, LR &lr, rmd_lean_t &st, int szero, int slen, int r0, int cnt )
+{
+	st.szero = szero;
+	st.slen = slen;
+	st.rank = -1;
+	st.order = 0;
+	int	d0 = rmd_imin( szero + P->w_winsize - 1, slen - 1 ) - szero;
+	rmd_lrec_t	r = rmd_lean_open( P, 0, 0, d0 );
+	const rmd_elem_t	&stp = P->elems[ P->searches[ 0 ] ];
+	st.hi0 = r.sd;
+	st.lo0 = stp.minglen - 1;
+	if( r0 > 0 || cnt != RMD_ALL_RANKS ){
+		r.sd = int16_t( st.hi0 - r0 );
+		if( cnt < st.hi0 - st.lo0 + 1 && r.sd - cnt + 1 > st.lo0 )
+			st.lo0 = r.sd - cnt + 1;
+	}
+	lr.set( 0, r );
+	return 0;
+}
+
+// Rebuild the element table of the current path into L and run the end-of-list
+// checks (find_ss :362-393); called only for complete structural matches.
+template< class LR, class Sink >
+RMD_FN void rmd_lean_emit( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const rmd_seq_t &sq, rmd_lane_t *L, Sink &sink )
+{
+	const int	z = st.szero;
+	for( int k = 0; k < P->n_searches; k++ ){
+		const rmd_lrec_t	r = lr.get( k );
+		const int	d = P->searches[ k ];
+		const rmd_elem_t	&stp = P->elems[ d ];
+		const int	zero = z + r.zero, cur = z + r.sd + 1;
+		if( stp.type == RMA_T_SS ){
+			int	mm = 0;
+			if( stp.re >= 0 && stp.mismatch > 0 )
+				rmd_chk_seq( P, stp, sq, zero, cur - zero + 1, &mm );
+			L->moff[ d ] = zero;
+			L->mlen[ d ] = cur - zero + 1;
+			L->mpr[ d ] = 0;
+			L->mm[ d ] = int16_t( mm );
+		}else{
+			const int	d3 = stp.mates[ 0 ], hl = r.hl;
+			uint64_t	cand, mis;
+			int	mm5 = 0, mm3 = 0;
+			rmd_match_wchlx_mm( P, sq, d, d3, zero, cur, rmd_s3lim( zero, cur, stp.minilen, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
+			int	mpr = rmd_popc64( mis & ( ( 1ull << hl ) - 1 ) );
+			L->moff[ d ] = zero;
+			L->mlen[ d ] = hl;
+			L->moff[ d3 ] = cur - hl + 1;
+			L->mlen[ d3 ] = hl;
+			L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
+			L->mm[ d ] = int16_t( mm5 );
+			L->mm[ d3 ] = int16_t( mm3 );
+		}
+	}
+	L->slen = st.slen;
+	L->szero = z;
+	L->rank = st.rank;
+	L->order = st.order;
+	L->l_mm = L->r_mm = RMD_UNDEF;
+	L->l_off = L->l_len = L->r_off = L->r_len = 0;
+	if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
+		return;
+	if( !rmd_set_context( P, L, sq ) )
+		return;
+	if( !rmd_chk_sites( P, L, sq ) )
+		return;
+	sink.put( P, L, z );
+	st.order++;
+}
+
+// One transition at level k; returns the next level, -1 when the item is done.
+template< class LR, class Sink >
+RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const rmd_seq_t &sq, int k,
+	rmd_lane_t *L, Sink &sink )
+{
+	const int	d = P->searches[ k ];
+	const rmd_elem_t	&stp = P->elems[ d ];
+	const int	is_ss = stp.type == RMA_T_SS;
+	const int	z = st.szero;
+	rmd_lrec_t	r = lr.get( k );
+	uint64_t	cand = 0, mis = 0;
+	int	cur;
+
+	if( r.ph != 0 ){
+		r.ph = 0;
+		if( !is_ss ){
+			// back at a helix: its remaining lengths at the same end position
+			cur = r.sd + 1;
+			int	mm5 = 0, mm3 = 0;
+			rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
+				rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 );
+			cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+		}
+	}
+	for( ; ; ){
+		if( cand == 0 ){
+			// next end position, find_motif :273
+			int	lo = stp.loop ? r.zero + stp.minglen - 1 : r.osd;
+			if( k == 0 && st.lo0 > lo )
+				lo = st.lo0;
+			if( stp.quick ){
+				while( r.sd >= lo && !rmd_quick_wchlx( P, stp, sq, z + r.zero, z + r.sd,
+					rmd_s3lim( r.zero, r.sd, stp.q_iminl, stp.maxlen ) + z ) )
+					r.sd--;
+			}
+			if( r.sd < lo )
+				return k - 1;
+			cur = r.sd--;
+			if( stp.loop ){
+				if( k == 0 ){
+					st.rank = st.hi0 - cur;
+					st.order = 0;
+				}
+				if( stp.next_s >= 0 )
+					lr.set( stp.next_s, rmd_lean_open( P, stp.next_s, cur + 1, r.osd ) );
+			}
+			if( is_ss ){
+				const int	len = cur - r.zero + 1;
+				if( len < stp.minlen || len > stp.maxlen )
+					continue;
+				if( stp.re >= 0 ){
+					int	mm = 0;
+					if( !rmd_chk_seq( P, stp, sq, z + r.zero, len, &mm ) )
+						continue;
+				}
+				if( k < P->n_searches - 1 ){
+					// the next level's window may have been written long ago (end of an
+					// inner chain) and its iterator used up since: start it afresh
+					rmd_lrec_t	c = lr.get( k + 1 );
+					c = rmd_lean_open( P, k + 1, c.zero, c.osd );
+					// look ahead: if the next level is a helix and none of its end
+					// positions can start it, this length of the ss leads nowhere
+					const rmd_elem_t	&nx = P->elems[ P->searches[ k + 1 ] ];
+					if( nx.quick ){
+						const int	nlo = nx.loop ? c.zero + nx.minglen - 1 : c.osd;
+						while( c.sd >= nlo && !rmd_quick_wchlx( P, nx, sq, z + c.zero, z + c.sd,
+							rmd_s3lim( c.zero, c.sd, nx.q_iminl, nx.maxlen ) + z ) )
+							c.sd--;
+						if( c.sd < nlo )
+							continue;
+					}
+					r.ph = 1;
+					lr.set( k, r );
+					lr.set( k + 1, c );
+					return k + 1;
+				}
+				r.ph = 1;
+				lr.set( k, r );
+				rmd_lean_emit( P, lr, st, sq, L, sink );
+				return k;
+			}
+			int	mm5 = 0, mm3 = 0;
+			if( !rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
+				rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 ) ){
+				cand = 0;
+				continue;
+			}
+		}
+		// helix: next accepted length, find_wchlx :435-460
+		const int	hl = rmd_ctz64( cand );
+		cand &= cand - 1;
+		if( cur - r.zero - 2 * hl + 1 > stp.maxilen )
+			continue;
+		r.hl = uint8_t( hl );
+		r.ph = 1;
+		lr.set( k, r );
+		lr.set( stp.inner_s, rmd_lean_open( P, stp.inner_s, r.zero + hl, cur - hl ) );
+		return k + 1;
+	}
 }

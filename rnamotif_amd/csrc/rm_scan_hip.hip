@@ -76,12 +76,20 @@ struct DevSink {
 
 #define PROG_LDS_BYTES	( ( sizeof( rmd_program_t ) + 15 ) & ~size_t( 15 ) )
 #ifndef QCAP
-#define QCAP		2048		// work queue entries per workgroup
+#define QCAP		1024		// work queue entries per workgroup
 #endif
+
+// lean path records of one lane: level k at base[ k * BLOCK ] (lane-contiguous 8-byte slots)
+template< int BLOCK >
+struct LdsRecs {
+	rmd_lrec_t	*base;
+	__device__ inline rmd_lrec_t	get( int k ) const { return base[ k * BLOCK ]; }
+	__device__ inline void	set( int k, rmd_lrec_t v ) { base[ k * BLOCK ] = v; }
+};
 
 // ---------------------------------------------------------------- search kernel
 #ifndef SEARCH_WAVES_PER_SIMD
-#define SEARCH_WAVES_PER_SIMD	5
+#define SEARCH_WAVES_PER_SIMD	4
 #endif
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
@@ -123,6 +131,8 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + PROG_LDS_BYTES + QCAP * sizeof( unsigned ) +
 		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
 	unsigned long long	*occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
+	rmd_lrec_t	*lean = reinterpret_cast<rmd_lrec_t *>( occ + pb_words );
+	const bool	lean_mode = P->lean_ok && !( dbg & 16 );
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
 	const int	lit_n = lit ? P->regexes[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
@@ -367,6 +377,34 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
 		int	k = -1;
 		bool	dry = false;
+		if( lean_mode ){
+			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
+			LdsRecs<BLOCK>	lr{ lean + tid };
+			rmd_lean_t	st;
+			for( ; ; ){
+				const unsigned long long	want = __ballot( k < 0 && !dry );
+				if( want ){
+					int	base = 0;
+					if( lane_id == __ffsll( want ) - 1 )
+						base = atomicAdd( &s_qhead, __popcll( want ) );
+					base = __shfl( base, __ffsll( want ) - 1 );
+					if( k < 0 && !dry ){
+						const int	i = base + __popcll( want & lt_mask );
+						if( i < nq ){
+							const unsigned	item = queue[ i ];
+							const int	r = int( item & 0xffffu );
+							k = rmd_lean_begin( P, lr, st, z0 + int( item >> 16 ), slen,
+								r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+						}else
+							dry = true;
+					}
+				}
+				if( __ballot( k >= 0 ) == 0 )
+					break;
+				if( k >= 0 )
+					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink );
+			}
+		}else
 		for( ; ; ){
 			const unsigned long long	want = __ballot( k < 0 && !dry );
 			if( want ){
@@ -440,7 +478,7 @@ struct rma_scanner {
 	int64_t	hit_cap = 0;
 	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
 	std::vector<int32_t>	h_raw, h_sorted;
-	int	tile_t = 4096;
+	int	tile_t = 2048;
 	int	grid_blocks = 0;
 };
 
@@ -660,6 +698,8 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
 	size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = PROG_LDS_BYTES + QCAP * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
+	if( dp.lean_ok )
+		lds += size_t( dp.n_searches ) * BLOCK * sizeof( rmd_lrec_t );
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;

@@ -27,6 +27,25 @@ struct VecSink {
 	}
 };
 
+struct ArrRecs {
+	rmd_lrec_t	r[ RMD_LEAN_LEVELS ];
+	rmd_lrec_t	get( int k ) const { return r[ k ]; }
+	void	set( int k, rmd_lrec_t v ) { r[ k ] = v; }
+};
+
+// one work item, through the lean path when the descriptor allows it
+static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t &sq, int szero, int slen, int r0, int cnt, VecSink &sink )
+{
+	if( dp->lean_ok && !getenv( "HOSTSIM_NOLEAN" ) ){
+		ArrRecs	recs;
+		rmd_lean_t	st;
+		int	k = rmd_lean_begin( dp, recs, st, szero, slen, r0, cnt );
+		while( k >= 0 )
+			k = rmd_lean_step( dp, recs, st, sq, k, lane, sink );
+	}else
+		rmd_search_position( dp, lane, sq, szero, slen, r0, cnt, sink );
+}
+
 static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int slen, int comp, std::vector<int32_t> &out )
 {
 	std::vector<uint8_t>	codes( slen + 1 );
@@ -71,7 +90,7 @@ static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int sl
 				( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
 			if( !getenv( "HOSTSIM_NOQUICK" ) && at_szero && !rmd_prefix_ok( dp, e0, sq, szero ) )
 				continue;
-			rmd_search_position( dp, &lane, sq, szero, slen, 0, RMD_ALL_RANKS, sink );
+			sim_item( dp, &lane, sq, szero, slen, 0, RMD_ALL_RANKS, sink );
 			continue;
 		}
 		int	hi, lo;
@@ -79,7 +98,7 @@ static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int sl
 		for( int sd = hi; sd >= lo; sd-- ){
 			int	s3lim = rmd_s3lim( szero, sd, i_minl0, e0.maxlen );
 			if( rmd_quick_wchlx( dp, e0, sq, szero, sd, s3lim ) )
-				rmd_search_position( dp, &lane, sq, szero, slen, hi - sd, 1, sink );
+				sim_item( dp, &lane, sq, szero, slen, hi - sd, 1, sink );
 		}
 	}
 }

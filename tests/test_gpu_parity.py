@@ -111,3 +111,86 @@ def test_syn10m_hit_counts(built, workdir):
     total = ln.sum(axis=1)
     assert np.all((total >= d.minlen) & (total <= d.maxlen))
     assert np.all(off[:, 0] == hits[:, 2])
+
+
+def _descr(workdir, name, extra=()):
+    import rnamotif_amd as R
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        return R.Descriptor(list(extra) + ["-descr", name])
+    finally:
+        os.chdir(cwd)
+
+
+SYN_DESCR = ["trna.descr", "pk1.descr", "pk_j1+2.descr", "qu+tr.descr", "ire.descr", "mp.ends.descr",
+             "bulge.descr", "nanlin.descr", "score.1.descr", "sprintf.descr"]
+
+
+@pytest.mark.parametrize("name", SYN_DESCR)
+def test_synthetic_records_equal_oracle(built, workdir, name):
+    """Random sequence (no biology: the pre-filters see their worst case mix of
+    near misses) -- records bit-identical to the oracle, record boundaries that
+    are not multiples of the tile or of 32 bases."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(11)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    seqs = [lut[rng.integers(0, 4, size=n)].tobytes() for n in (300_001, 4097, 2048, 2047, 131_071, 33)]
+    d = _descr(workdir, name)
+    sc = R.Scanner(d)
+    got = sc.scan(sc.database(seqs))
+    want = oracle_scan(d, seqs)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dbg", [4, 8, 16, 28])
+@pytest.mark.parametrize("name", ["trna.descr", "pk1.descr", "qu+tr.descr"])
+def test_search_paths_agree(built, workdir, name, dbg):
+    """The kernel's optional stages (4: bit-parallel pre-filter off, 8: literal
+    filter off, 16: LDS-record search off -> general state machine) are output
+    neutral: every combination gives the oracle's records."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(12)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    seqs = [lut[rng.integers(0, 4, size=n)].tobytes() for n in (150_000, 5000)]
+    d = _descr(workdir, name)
+    want = oracle_scan(d, seqs)
+    sc = R.Scanner(d)
+    db = sc.database(seqs)
+    old = os.environ.get("RNAMOTIF_DBG")
+    os.environ["RNAMOTIF_DBG"] = str(dbg)
+    try:
+        got = sc.scan(db)
+    finally:
+        if old is None:
+            del os.environ["RNAMOTIF_DBG"]
+        else:
+            os.environ["RNAMOTIF_DBG"] = old
+    assert np.array_equal(got, want)
+
+
+def test_tile_sizes_agree(built, workdir):
+    """Tile size is a launch parameter only: 256..8192 start positions per
+    workgroup give identical records."""
+    import rnamotif_amd as R
+    rng = np.random.default_rng(13)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    seqs = [lut[rng.integers(0, 4, size=n)].tobytes() for n in (400_000, 777)]
+    d = _descr(workdir, "trna.descr")
+    res = []
+    old = os.environ.get("RNAMOTIF_TILE")
+    try:
+        for t in (256, 1024, 2048, 8192):
+            os.environ["RNAMOTIF_TILE"] = str(t)
+            sc = R.Scanner(d)
+            res.append(sc.scan(sc.database(seqs)))
+    finally:
+        if old is None:
+            os.environ.pop("RNAMOTIF_TILE", None)
+        else:
+            os.environ["RNAMOTIF_TILE"] = old
+    for r in res[1:]:
+        assert np.array_equal(res[0], r)
