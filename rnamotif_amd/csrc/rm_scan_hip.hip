@@ -91,7 +91,10 @@ struct LdsRecs {
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
 #endif
-template< int BLOCK >
+// LEAN: the descriptor has only ss and proper helices (rmd_program_t::lean_ok) -- pass B keeps
+// 8 bytes of state per level in LDS; the general state machine is not compiled into that
+// instance at all (no scratch frames, fewer registers).
+template< int BLOCK, bool LEAN >
 __global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
 rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
@@ -132,7 +135,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
 	unsigned long long	*occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
 	rmd_lrec_t	*lean = reinterpret_cast<rmd_lrec_t *>( occ + pb_words );
-	const bool	lean_mode = P->lean_ok && !( dbg & 16 );
+	LdsRecs<BLOCK>	lr{ lean + threadIdx.x };
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
 	const int	lit_n = lit ? P->regexes[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
@@ -234,7 +237,12 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 				const int	slot_ = base_ + __popcll( m_ & lt_mask ); \
 				if( slot_ < QCAP ) \
 					queue[ slot_ ] = ( item ); \
-				else \
+				else if constexpr( LEAN ){ \
+					rmd_lean_t	st_; \
+					int	k_ = rmd_lean_begin( P, lr, st_, szero_, slen, r0_, cnt_ ); \
+					while( k_ >= 0 ) \
+						k_ = rmd_lean_step( P, lr, st_, sq, k_, &lane, sink ); \
+				}else \
 					rmd_search_position( P, &lane, sq, szero_, slen, r0_, cnt_, sink ); \
 			} \
 		} }while( 0 )
@@ -377,9 +385,8 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
 		int	k = -1;
 		bool	dry = false;
-		if( lean_mode ){
+		if constexpr( LEAN ){
 			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
-			LdsRecs<BLOCK>	lr{ lean + tid };
 			rmd_lean_t	st;
 			for( ; ; ){
 				const unsigned long long	want = __ballot( k < 0 && !dry );
@@ -698,13 +705,16 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
 	size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = PROG_LDS_BYTES + QCAP * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
-	if( dp.lean_ok )
+	const int	dbg = getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0;
+	const bool	lean = dp.lean_ok && !( dbg & 16 );
+	if( lean )
 		lds += size_t( dp.n_searches ) * BLOCK * sizeof( rmd_lrec_t );
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;
 	}
-	HIPCHK( hipFuncSetAttribute( reinterpret_cast<const void *>( &rma_search_kernel<BLOCK> ),
+	HIPCHK( hipFuncSetAttribute( lean ? reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, true> ) :
+		reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, false> ),
 		hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	int	grid = int( std::min<int64_t>( db->n_tiles, sc->grid_blocks ) );
 	unsigned long long	count = 0;
@@ -712,8 +722,12 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 4 * sizeof( unsigned long long ), sc->stream ) );
 		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
-		hipLaunchKernelGGL( rma_search_kernel<BLOCK>, dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-			sc->d_prog, v, hb, tile_bytes, getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0 );
+		if( lean )
+			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
+				sc->d_prog, v, hb, tile_bytes, dbg );
+		else
+			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, false> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
+				sc->d_prog, v, hb, tile_bytes, dbg );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );
