@@ -42,6 +42,25 @@ def synthetic_slice(first: int, count: int, length: int):
     return out
 
 
+def profiled_traffic(kernel="rma_search_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes (profiles/r01_final_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE in
+    separate passes over this same default workload, in KiB).  Corrected as
+    MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies 128-byte
+    requests at 64 bytes -> doubled; WRITE_SIZE is exact."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    kb = {}
+    for r in csv.DictReader(open(path)):
+        if kernel in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            kb[r["counter"]] = float(r["mean_per_dispatch"])
+    if len(kb) != 2:
+        return None
+    return int(2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024)
+
+
 def cpu_baseline(descr, seqs, budget_bases):
     """The scalar CPU oracle (kind 'port': byte-identical to the reference on
     its golden tests, and within a few percent of its speed here) on a bounded
@@ -69,7 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--records", type=int, default=100, help="1 Mbase records per GPU (default 100 = 100 Mbase)")
     ap.add_argument("--record-len", type=int, default=1_000_000)
-    ap.add_argument("--descr", default=os.path.join(ROOT, "tests", "golden", "descr", "trna.descr"))
+    ap.add_argument("--descr", default=os.path.join(ROOT, "tests", "golden", "descr", "trna.descr"),
+                    help="descriptor file; a comma separated list = mixed batch (every descriptor over the same database)")
     ap.add_argument("--cpu-bases", type=int, default=12_000_000, help="sample size of the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -91,13 +111,17 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
-    descr = R.Descriptor(["-descr", args.descr])
+    default_workload = (args.descr == ap.get_default("descr") and args.records == 100 and
+                        args.record_len == 1_000_000)
+    descr_files = args.descr.split(",")
+    descrs = [R.Descriptor(["-descr", f]) for f in descr_files]
+    descr = descrs[0]
     seqs = synthetic_slice(rank * args.records, args.records, args.record_len)
-    sc = R.Scanner(descr, device=local_rank)
-    db = sc.database(seqs)
-    stride = descr.hit_stride
+    scs = [R.Scanner(d, device=local_rank) for d in descrs]
+    dbs = [s.database(seqs) for s in scs]
+    sc, db = scs[0], dbs[0]
 
-    def gather_hits(h):
+    def gather_hits(h, stride):
         """Variable length gather of hit records to rank 0 (RCCL send/recv)."""
         if world == 1:
             return h
@@ -120,8 +144,10 @@ def main():
         return h
 
     def step():
-        h = sc.scan(db)
-        return gather_hits(h)
+        n = 0
+        for d_, sc_, db_ in zip(descrs, scs, dbs):
+            n += gather_hits(sc_.scan(db_), d_.hit_stride).shape[0]
+        return n
 
     for _ in range(args.warmup):
         step()
@@ -135,7 +161,7 @@ def main():
     t0 = time.perf_counter()
     total_hits = 0
     for _ in range(args.steps):
-        total_hits = step().shape[0]
+        total_hits = step()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -146,19 +172,24 @@ def main():
     # kernel time of the dominant kernel, HIP events on the scanner's own stream
     kms = []
     for _ in range(max(1, min(args.steps, 3))):
-        n_cand, search_ms, efn_ms = sc.scan_device(db)
-        kms.append((search_ms, efn_ms))
+        tot = [0.0, 0.0]
+        for sc_, db_ in zip(scs, dbs):
+            n_cand, s_ms, e_ms = sc_.scan_device(db_)
+            tot[0] += s_ms
+            tot[1] += e_ms
+        kms.append(tuple(tot))
     search_ms = float(np.mean([k[0] for k in kms]))
     efn_ms = float(np.mean([k[1] for k in kms]))
 
     if rank == 0:
         bases_per_gpu = db.bases
-        total_bases = bases_per_gpu * world
+        total_bases = bases_per_gpu * world * len(descrs)   # mixed batch: every descriptor scans every base
         ms_per_step = dt / args.steps * 1e3
         value = total_bases / (dt / args.steps) / 1e6
-        achieved = ALGO_BYTES_PER_BASE * bases_per_gpu / (search_ms * 1e-3) / 1e9
+        achieved = ALGO_BYTES_PER_BASE * bases_per_gpu * len(descrs) / (search_ms * 1e-3) / 1e9
+        names = "+".join(os.path.basename(f) for f in descr_files)
         out = {
-            "metric": "Mbases scanned/sec (whole node) + hits/sec, trna.descr",
+            "metric": "Mbases scanned/sec (whole node) + hits/sec, " + names,
             "value": round(value, 3),
             "unit": "Mbases/s",
             "hits_per_s": round(total_hits / (dt / args.steps), 2),
@@ -172,7 +203,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{os.path.basename(args.descr)} (descr/trna.descr: 15 elements, bits()+efn() score) over "
+                "workload": f"{names} ({'mixed batch, ' if len(descrs) > 1 else ''}{'+'.join(str(d.n_elems) for d in descrs)} elements) over "
                             f"{args.records} x {args.record_len} base synthetic records per GPU "
                             f"(iid uniform acgt, numpy default_rng(20240601)), both strands",
                 "bases_per_gpu": bases_per_gpu,
@@ -187,12 +218,15 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 8),
-                "traffic": None,
+                "traffic": profiled_traffic() if default_workload and world == 1 else None,
+                "traffic_note": "bytes per launch from the committed PMC passes of this workload "
+                                "(profiles/r01_final_pmc_summary.csv), 2 x FETCH_SIZE + WRITE_SIZE",
+                "algorithmic_bytes": int(ALGO_BYTES_PER_BASE * bases_per_gpu * len(descrs)),
                 "kernel_ms": round(search_ms, 3),
                 "efn_kernel_ms": round(efn_ms, 3),
                 "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE,
                 "note": "the search is integer/LDS issue bound, not HBM bound (SURVEY.md 8d); "
-                        "kernel-only rate = %.1f Mbases/s" % (bases_per_gpu / (search_ms * 1e-3) / 1e6),
+                        "kernel-only rate = %.1f Mbases/s" % (bases_per_gpu * len(descrs) / (search_ms * 1e-3) / 1e6),
             },
         }
         if world == 1 and args.cpu_bases > 0:

@@ -268,3 +268,25 @@ def synthetic_records(k: int, length: int = 1_000_000, seed: int = 20240601) -> 
     rng = np.random.default_rng(seed)
     lut = np.frombuffer(b"acgt", dtype=np.uint8)
     return [lut[rng.integers(0, 4, size=length)].tobytes() for _ in range(k)]
+
+
+def write_synthetic_fasta(path: str, k: int, length: int = 1_000_000, seed: int = 20240601) -> str:
+    """The synthetic database as a FASTA file in the layout SURVEY.md section 8d
+    fixes (ids syn%04d, upper case, 50 columns); k=10 gives the survey's syn10M
+    (md5 d33c2542e515346e1d0fdfc9edcc5658).  Returns the md5 of the file."""
+    import hashlib
+    h = hashlib.md5()
+    with open(path, "wb") as f:
+        for i, s in enumerate(synthetic_records(k, length, seed)):
+            head = b">syn%04d synthetic uniform ACGT seed=%d len=%d\n" % (i, seed, length)
+            a = np.frombuffer(s.upper(), dtype=np.uint8)
+            full = (len(a) // 50) * 50
+            body = np.concatenate([a[:full].reshape(-1, 50),
+                                   np.full((full // 50, 1), 10, dtype=np.uint8)], axis=1).tobytes()
+            if full < len(a):
+                body += a[full:].tobytes() + b"\n"
+            f.write(head)
+            f.write(body)
+            h.update(head)
+            h.update(body)
+    return h.hexdigest()

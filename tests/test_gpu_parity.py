@@ -194,3 +194,29 @@ def test_tile_sizes_agree(built, workdir):
             os.environ["RNAMOTIF_TILE"] = old
     for r in res[1:]:
         assert np.array_equal(res[0], r)
+
+
+SYN10M_FIRST_TRNA = (b"syn0000         1.981  -12.300 0   59767   82 cgagcc tt ctt taca gag a catg acggaac catg "
+                     b"caatccggcaccggagtgaga aggct gttgggc agtct ggcttg catg")
+
+
+@pytest.mark.parametrize("name", sorted(pins.SYN10M))
+def test_syn10m_cli_hit_counts(built, workdir, tmp_path_factory, name):
+    """The reference's own numbers on syn10M (measured with the
+    unmodified reference sources): hits printed by the command line program on
+    the same file -- trna 630, pk1 1039, qu+tr 155, mp.ends 36, ire 3."""
+    import rnamotif_amd as R
+    d = tmp_path_factory.getbasetemp() / "syn10M"
+    d.mkdir(exist_ok=True)
+    fa = d / "syn10M.fastn"
+    if not fa.exists():
+        assert R.write_synthetic_fasta(str(fa), 10) == "d33c2542e515346e1d0fdfc9edcc5658"
+    env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    p = subprocess.run([built["cli"], "-descr", name, str(fa)], cwd=workdir, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+    assert p.returncode == 0, p.stderr.decode()
+    lines = p.stdout.split(b"\n")
+    assert sum(1 for l in lines if l.startswith(b">")) == pins.SYN10M[name]
+    if name == "trna.efn.descr":
+        first = [l for l in lines if l.startswith(b"syn")][0]
+        assert b" ".join(first.split()) == b" ".join(SYN10M_FIRST_TRNA.split())
