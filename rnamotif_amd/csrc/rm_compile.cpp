@@ -261,6 +261,12 @@ Ident *Descriptor::find_id( const char *name )	// :1752
 	return it == globals.end() ? nullptr : it->second;
 }
 
+int Descriptor::int_global( const char *name, int dflt )
+{
+	Ident	*ip = find_id( name );
+	return ip != nullptr && ip->type == T_INT ? ip->val.ival : dflt;
+}
+
 // ---------------------------------------------------------------- pair sets
 void Descriptor::mk_mats( PairSet *ps )	// mk_bmatp :2520, mk_rbmatp :2581
 {

@@ -106,6 +106,8 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 	std::vector<SeqRecord>	batch;
 	int64_t	in_batch = 0;
 	char	err[ 1024 ];
+	int	ecnt = 0;
+	const int	show_progress = d.int_global( "show_progress", 0 );
 	auto flush = [&](){
 		if( batch.empty() )
 			return;
@@ -134,9 +136,19 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 				break;
 			}
 		}
-		FastaReader	rd( fp, d.args.maxslen );
+		FastaReader	rd( fp, d.args.maxslen, seq_format_of( d.args.dbfmt ) );
 		SeqRecord	rec;
-		while( rd.next( rec ) ){
+		for( ; ; ){
+			const bool	got = rd.next( rec );
+			// rnamot.c:160-176: the entry counter also ticks for the EOF that switches to
+			// the next file (with an empty name), not for the one that ends the run
+			if( !got && ( use_stdin || f + 1 >= nfiles ) )
+				break;
+			ecnt++;
+			if( show_progress > 0 && ecnt % show_progress == 0 )
+				fprintf( stderr, "%s: %7d: %s\n", d.args.argv0.c_str(), ecnt, got ? rec.sid.c_str() : "" );
+			if( !got )
+				break;
 			st.n_seqs++;
 			st.n_bases += int64_t( rec.seq.size() );
 			in_batch += int64_t( rec.seq.size() );

@@ -15,14 +15,24 @@ struct SeqRecord {
 	bool	eof = false;		// FN_fgetseq returned EOF (no record)
 };
 
+// -fmt fastn | pir | gb (rnamot.c:126-138): FN_fgetseq dbutil.c:42, PIR_fgetseq :130,
+// GB_fgetseq :226
+enum SeqFormat { FMT_FASTN = 0, FMT_PIR = 1, FMT_GENBANK = 2 };
+SeqFormat seq_format_of( const std::string &name );	// "" and "fastn" -> FMT_FASTN
+
 class FastaReader {
 public:
-	explicit FastaReader( FILE *fp, int maxslen = 30000001 ) : fp_( fp ), maxslen_( maxslen ) {}
+	explicit FastaReader( FILE *fp, int maxslen = 30000001, SeqFormat fmt = FMT_FASTN ) :
+		fp_( fp ), maxslen_( maxslen ), fmt_( fmt ) {}
 	// returns false at end of file; diagnostics go to stderr like the reference
 	bool	next( SeqRecord &rec );
 private:
+	bool	next_fastn( SeqRecord &rec );
+	bool	next_pir( SeqRecord &rec );
+	bool	next_gb( SeqRecord &rec );
 	FILE	*fp_;
 	int	maxslen_;
+	SeqFormat	fmt_;
 };
 
 // Packed database layout (device side):

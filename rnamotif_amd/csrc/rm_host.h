@@ -131,6 +131,7 @@ struct Args {						// ARGS_T, getargs.c
 	float	o_emin = 2.5f;
 	std::vector<std::string>	incdirs;
 	std::string	dfname, xdfname, cldefs, dbfmt;
+	std::string	argv0 = "rnamotif";
 	bool	have_dfname = false, have_xdfname = false;
 	std::vector<std::string>	dbfnames;
 };
@@ -174,6 +175,7 @@ struct Descriptor {
 	// symbol table, compile.c:1685-1795
 	Ident	*enter_id( const char *name, int type, int scope, int reinit, const Value *vp );
 	Ident	*find_id( const char *name );
+	int	int_global( const char *name, int dflt );	// value of an int global (show_progress ...)
 
 	// parser actions, compile.c
 	void	parm_add( Node *expr );			// PARM_add :396

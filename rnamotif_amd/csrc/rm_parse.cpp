@@ -53,6 +53,8 @@ const char	*USAGE_FMT =
 Args parse_args( int argc, char **argv )
 {
 	Args	a;
+	if( argc > 0 && argv[ 0 ] != nullptr )
+		a.argv0 = argv[ 0 ];
 	auto usage = [&]() {
 		char	buf[ 4096 ];
 		snprintf( buf, sizeof( buf ), USAGE_FMT, argv[ 0 ] );
