@@ -247,6 +247,64 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		if( !( e.type == RMA_T_SS || ( e.type == RMA_T_H5 && e.proper ) ) )
 			out->lean_ok = 0;
 	}
+	for( int d = 0; d < p->n_elems; d++ ){
+		out->elems[ d ].rem_min = 0;
+		out->elems[ d ].rem_max = -1;
+		out->elems[ d ].tail_s = -1;
+		out->elems[ d ].tail_pre_min = 0;
+		out->elems[ d ].tail_pre_max = -1;
+	}
+	if( out->lean_ok ){
+		// The reference walks a chain left to right and only learns at its end that the
+		// remaining groups do not fit.  Both bounds below are implied by the hard length
+		// limits find_motif() itself applies (find_motif.c:266-273, :423-440), so cutting
+		// with them only skips branches that cannot produce a candidate.
+		for( int s = 1; s < p->n_searches; s++ ){
+			rmd_elem_t	*d = &out->elems[ p->searches[ s ] ];
+			long	mn = 0, mx = 0;
+			bool	unb = false;
+			int	last = s;
+			for( int j = d->next_s; j >= 0; j = out->elems[ p->searches[ j ] ].next_s ){
+				const rmd_elem_t	&ej = out->elems[ p->searches[ j ] ];
+				mn += ej.minglen;
+				if( ej.maxglen == RMA_UNBOUNDED )
+					unb = true;
+				else
+					mx += ej.maxglen;
+				last = j;
+			}
+			const bool	closed = !out->elems[ p->searches[ last ] ].loop;
+			if( d->loop && mn < 30000 )
+				d->rem_min = int16_t( mn );
+			if( d->loop && closed && !unb && mx < 30000 )
+				d->rem_max = int16_t( mx );
+		}
+		for( int s = 0; s < p->n_searches; s++ ){
+			rmd_elem_t	*d = &out->elems[ p->searches[ s ] ];
+			if( d->type != RMA_T_H5 || d->inner_s < 0 )
+				continue;
+			long	mn = 0, mx = 0;
+			bool	unb = false;
+			int	t = d->inner_s;
+			for( ; ; ){
+				const rmd_elem_t	&ej = out->elems[ p->searches[ t ] ];
+				if( ej.next_s < 0 )
+					break;
+				mn += ej.minglen;
+				if( ej.maxglen == RMA_UNBOUNDED )
+					unb = true;
+				else
+					mx += ej.maxglen;
+				t = ej.next_s;
+			}
+			const rmd_elem_t	&te = out->elems[ p->searches[ t ] ];
+			if( t != d->inner_s && te.quick && te.type == RMA_T_H5 && !te.loop && te.minlen >= 1 && mn < 30000 ){
+				d->tail_s = int8_t( t );
+				d->tail_pre_min = int16_t( mn );
+				d->tail_pre_max = ( unb || mx >= 30000 ) ? int16_t( -1 ) : int16_t( mx );
+			}
+		}
+	}
 	for( int s = 0; s < p->n_sites; s++ ){
 		rmd_site_t	*d = &out->sites[ s ];
 		d->n_pos = int8_t( p->sites[ s ].n_pos );

@@ -60,6 +60,13 @@ struct rmd_elem_t {
 	int32_t	mismatch;
 	int32_t	mplim;			// match_wchlx/match_phlx mispair limit
 	int32_t	rule;			// index into rules[] (helix strands), else 0
+	// search-space pruning of the lean path (necessary conditions, output neutral):
+	int16_t	rem_min;		// least total length of the groups that follow in the chain
+	int16_t	rem_max;		// most (closed chains only), -1: unknown / open chain
+	int8_t	tail_s;			// helix: level of the last group of its interior if that is a
+					// proper helix (its 3' end is pinned to the interior's end), else -1
+	int8_t	pad_[ 3 ];
+	int16_t	tail_pre_min, tail_pre_max;	// total length of the interior groups before it (-1: unbounded)
 };
 
 // length dependent helix rules, shared by the strands of one helix

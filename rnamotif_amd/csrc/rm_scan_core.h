@@ -1140,6 +1140,38 @@ struct rmd_lean_t {
 	int32_t	rank, order;
 };
 
+// The interior [a, b] (relative to z) of helix stp ends with a proper helix whose 3' strand
+// must end at b: can any of its admissible 5' ends start it?
+RMD_FN bool rmd_tail_ok( const rmd_program_t *P, const rmd_elem_t &stp, const rmd_seq_t &sq, int z, int a, int b )
+{
+	const rmd_elem_t	&t = P->elems[ P->searches[ stp.tail_s ] ];
+	int	s_hi = b - t.minglen + 1;
+	int	s_lo = t.maxglen == RMA_UNBOUNDED ? a : b - t.maxglen + 1;
+	if( a + stp.tail_pre_min > s_lo )
+		s_lo = a + stp.tail_pre_min;
+	if( stp.tail_pre_max >= 0 && a + stp.tail_pre_max < s_hi )
+		s_hi = a + stp.tail_pre_max;
+	for( int s = s_hi; s >= s_lo; s-- )
+		if( rmd_quick_wchlx( P, t, sq, z + s, z + b, rmd_s3lim( s, b, t.q_iminl, t.maxlen ) + z ) )
+			return true;
+	return false;
+}
+
+// Level 0 in the pre-filter: the helix length is not known yet -- any length will do.
+RMD_FN bool rmd_tail_any( const rmd_program_t *P, const rmd_elem_t &stp, const rmd_seq_t &sq, int szero, int sd )
+{
+	if( stp.tail_s < 0 )
+		return true;
+	for( int hl = stp.minlen; hl <= stp.maxlen; hl++ ){
+		const int	ilen = sd - szero + 1 - 2 * hl;
+		if( ilen < stp.minilen )
+			break;
+		if( ilen <= stp.maxilen && rmd_tail_ok( P, stp, sq, szero, hl, sd - szero - hl ) )
+			return true;
+	}
+	return false;
+}
+
 RMD_FN rmd_lrec_t rmd_lean_open( const rmd_program_t *P, int level, int zero, int osd )	// rmd_enter()
 {
 	const rmd_elem_t	&stp = P->elems[ P->searches[ level ] ];
@@ -1147,6 +1179,8 @@ RMD_FN rmd_lrec_t rmd_lean_open( const rmd_program_t *P, int level, int zero, in
 	int	hi = osd;
 	if( stp.loop && stp.maxglen != RMA_UNBOUNDED && zero + stp.maxglen - 1 < hi )
 		hi = zero + stp.maxglen - 1;
+	if( osd - stp.rem_min < hi )		// the groups that follow need room
+		hi = osd - stp.rem_min;
 	r.zero = int16_t( zero );
 	r.osd = int16_t( osd );
 	r.sd = int16_t( hi );
@@ -1254,6 +1288,8 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 		if( cand == 0 ){
 			// next end position, find_motif :273
 			int	lo = stp.loop ? r.zero + stp.minglen - 1 : r.osd;
+			if( stp.rem_max >= 0 && r.osd - stp.rem_max > lo )	// ... and must reach the chain's end
+				lo = r.osd - stp.rem_max;
 			if( k == 0 && st.lo0 > lo )
 				lo = st.lo0;
 			if( stp.quick ){
@@ -1318,6 +1354,8 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 		const int	hl = rmd_ctz64( cand );
 		cand &= cand - 1;
 		if( cur - r.zero - 2 * hl + 1 > stp.maxilen )
+			continue;
+		if( stp.tail_s >= 0 && !rmd_tail_ok( P, stp, sq, z, r.zero + hl, cur - hl ) )
 			continue;
 		r.hl = uint8_t( hl );
 		r.ph = 1;

@@ -88,6 +88,12 @@ struct LdsRecs {
 };
 
 // ---------------------------------------------------------------- search kernel
+#ifndef LEVEL_VOTE
+#define LEVEL_VOTE	0
+#endif
+#ifndef LEVEL_TIE
+#define LEVEL_TIE	&& c > 0
+#endif
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
 #endif
@@ -333,7 +339,9 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 						const bool	has = W != 0;
 						const int	i = has ? __ffsll( W ) - 1 : 0;
 						const int	r = r0 + 63 - i;
-						QPUSH( has, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+						// the interior's last helix is pinned to the 3' strand: test it now
+						const bool	keep = has && rmd_tail_any( P, e0, sq, szero, hi - r );
+						QPUSH( keep, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
 						W &= W - 1;
 					}
 				}
@@ -362,7 +370,8 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 				}else if( quick ){
 					const int	sd = hi - r;
 					const bool	pred = valid && sd >= lo &&
-						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) );
+						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) ) &&
+						rmd_tail_any( P, e0, sq, szero, sd );
 					QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
 				}else{
 					// helices whose 5' strand starts at the start position: its anchored
@@ -388,6 +397,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		if constexpr( LEAN ){
 			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
 			rmd_lean_t	st;
+			[[maybe_unused]] const int	n_lv = P->n_searches;
 			for( ; ; ){
 				const unsigned long long	want = __ballot( k < 0 && !dry );
 				if( want ){
@@ -408,8 +418,25 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 				}
 				if( __ballot( k >= 0 ) == 0 )
 					break;
+#if LEVEL_VOTE
+				// Lanes of a wave sit at different levels of different items.  Serve one
+				// level per round -- the most populated one (ties: the deepest) -- so that the
+				// element type and its loop bounds are uniform across the active lanes; the
+				// others wait and are joined by lanes that arrive at their level.
+				int	best = 0, best_n = -1;
+				for( int lv = 0; lv < n_lv; lv++ ){
+					const int	c = __popcll( __ballot( k == lv ) );
+					if( c >= best_n LEVEL_TIE ){
+						best_n = c;
+						best = lv;
+					}
+				}
+				if( k == best )
+					k = rmd_lean_step( P, lr, st, sq, best, &lane, sink );
+#else
 				if( k >= 0 )
 					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink );
+#endif
 			}
 		}else
 		for( ; ; ){
