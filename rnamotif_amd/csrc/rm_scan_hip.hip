@@ -339,9 +339,9 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 						const bool	has = W != 0;
 						const int	i = has ? __ffsll( W ) - 1 : 0;
 						const int	r = r0 + 63 - i;
-						// the interior's last helix is pinned to the 3' strand: test it now
-						const bool	keep = has && rmd_tail_any( P, e0, sq, szero, hi - r );
-						QPUSH( keep, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+						// (the pinned tail helix of the interior, rmd_tail_ok(), is left to pass B:
+						// tested here it costs more in this divergent loop than it saves there)
+						QPUSH( has, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
 						W &= W - 1;
 					}
 				}
@@ -370,8 +370,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 				}else if( quick ){
 					const int	sd = hi - r;
 					const bool	pred = valid && sd >= lo &&
-						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) ) &&
-						rmd_tail_any( P, e0, sq, szero, sd );
+						rmd_quick_wchlx( P, e0, sq, szero, sd, rmd_s3lim( szero, sd, i_minl0, e0.maxlen ) );
 					QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
 				}else{
 					// helices whose 5' strand starts at the start position: its anchored
