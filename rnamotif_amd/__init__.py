@@ -116,6 +116,11 @@ class Descriptor:
         self.minlen = L.rma_descr_minlen(h)
         self.maxlen = L.rma_descr_maxlen(h)
 
+    def search_order(self) -> List[int]:
+        """Element index heading each search level (rm_searches[k]->s_descr->s_index)."""
+        hdr = (C.c_int32 * (4 + self.n_searches)).from_address(self.program)   # magic, size, n_elems, n_searches, searches[]
+        return [int(x) for x in hdr[4:4 + self.n_searches]]
+
     def close(self) -> None:
         if self._h:
             lib().rma_descr_free(self._h)

@@ -37,10 +37,14 @@ int cli_main( int argc, char **argv, BackendFactory make_backend )
 {
 	try{
 		Args	args = parse_args( argc, argv );
-		if( args.vopt && !args.sopt ){
+		if( args.vopt )				// rnamot.c:56-65
 			fprintf( stderr, "%s: %s.\n", argv[ 0 ], VERSION_STR );
-			return 0;
+		if( args.sopt ){
+			std::unique_ptr<Descriptor>	d0 = init_only( args );
+			dump_descriptor( *d0, stderr, 2, 0, 0, 0 );
 		}
+		if( args.vopt || args.sopt )
+			return 0;
 		if( !args.have_dfname && !args.have_xdfname ){
 			fprintf( stderr, USAGE_FMT, argv[ 0 ] );
 			return 1;
@@ -58,6 +62,8 @@ int cli_main( int argc, char **argv, BackendFactory make_backend )
 			else
 				fprintf( stderr, "%d\n", d.dmaxlen );
 		}
+		if( args.dopt || args.hopt )		// rnamot.c:101-106
+			dump_descriptor( d, stderr, args.dopt, args.dopt, args.dopt, args.hopt );
 		if( args.dopt || args.popt )
 			d.score->dump( stderr );
 		if( args.copt )

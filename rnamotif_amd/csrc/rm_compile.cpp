@@ -1940,6 +1940,14 @@ void Descriptor::to_program( rma_program_t *out )
 	out->efn_stdbp = add_pairset( efnstdbp );
 }
 
+std::unique_ptr<Descriptor> init_only( const Args &args )
+{
+	std::unique_ptr<Descriptor>	d( new Descriptor );
+	d->args = args;
+	init_globals( *d );
+	return d;
+}
+
 std::unique_ptr<Descriptor> compile_descriptor( const Args &args )	// rnamot.c:49-98
 {
 	std::unique_ptr<Descriptor>	d( new Descriptor );

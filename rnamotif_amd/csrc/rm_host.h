@@ -254,5 +254,9 @@ bool	parse_descriptor( Descriptor &d, const std::string &text );
 std::unique_ptr<Descriptor>	compile_descriptor( const Args &args );
 
 const char	*strel_name( int type );		// RM_strel_name, dump.c:600
+// -s / -d / -h listings, RM_dump dump.c:34 (rm_dump.cpp)
+void	dump_descriptor( Descriptor &d, FILE *fp, int d_parms, int d_descr, int d_sites, int d_hierarchy );
+// a descriptor holding only the built-in symbols (RM_init, compile.c:157-394), for -s
+std::unique_ptr<Descriptor>	init_only( const Args &args );
 
 }	// namespace rma
