@@ -62,6 +62,27 @@ int	rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *sl
 void	rma_db_destroy( rma_db_t *db );
 int64_t	rma_db_bases( const rma_db_t *db );
 
+/* ---- packed database on disk (no counterpart in the reference, which re-reads the text
+ * on every run, rnamot.c:157-183): the readers' output -- names, definition lines and
+ * sequences as FN_/PIR_/GB_fgetseq deliver them (dbutil.c:42,130,226) -- stored in the
+ * layout rma_db_create() makes, plus the letters at ambiguous positions, so that a scan
+ * can start from it directly and print_match()'s text can still be rebuilt. */
+typedef struct rma_pack	rma_pack_t;
+int	rma_pack_write( const char *path, const char *const *sids, const char *const *sdefs,
+		const char *const *seqs, const int32_t *slens, int32_t n, char *err, size_t errlen );
+int	rma_pack_open( const char *path, rma_pack_t **out, char *err, size_t errlen );
+void	rma_pack_close( rma_pack_t *pk );
+int32_t	rma_pack_count( const rma_pack_t *pk );
+int64_t	rma_pack_bases( const rma_pack_t *pk );
+const char	*rma_pack_sid( const rma_pack_t *pk, int32_t i );
+const char	*rma_pack_sdef( const rma_pack_t *pk, int32_t i );
+int32_t	rma_pack_slen( const rma_pack_t *pk, int32_t i );
+/* buf must hold rma_pack_slen( pk, i ) + 1 bytes */
+int	rma_pack_seq( const rma_pack_t *pk, int32_t i, char *buf );
+/* entries [first, first+count) straight into HBM; hit records count entries from first */
+int	rma_db_create_packed( rma_scanner_t *sc, const rma_pack_t *pk, int32_t first, int32_t count,
+		rma_db_t **out, char *err, size_t errlen );
+
 /* ---- scan every sequence of db (both strands when the program says so).
  * *hits receives *n_hits records of rma_hit_stride( prog ) words, sorted by
  * (seq, comp, szero, rank, order) = the reference's output order; the memory

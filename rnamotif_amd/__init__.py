@@ -64,6 +64,21 @@ def lib() -> C.CDLL:
     L.rma_scanner_destroy.argtypes = [vp]
     L.rma_db_create.argtypes = [vp, cpp, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_db_destroy.argtypes = [vp]
+    L.rma_db_create_packed.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_pack_write.argtypes = [C.c_char_p, cpp, cpp, cpp, i32p, C.c_int32, C.c_char_p, C.c_size_t]
+    L.rma_pack_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_pack_close.argtypes = [vp]
+    L.rma_pack_count.argtypes = [vp]
+    L.rma_pack_count.restype = C.c_int32
+    L.rma_pack_bases.argtypes = [vp]
+    L.rma_pack_bases.restype = C.c_int64
+    L.rma_pack_sid.argtypes = [vp, C.c_int32]
+    L.rma_pack_sid.restype = vp
+    L.rma_pack_sdef.argtypes = [vp, C.c_int32]
+    L.rma_pack_sdef.restype = vp
+    L.rma_pack_slen.argtypes = [vp, C.c_int32]
+    L.rma_pack_slen.restype = C.c_int32
+    L.rma_pack_seq.argtypes = [vp, C.c_int32, C.c_char_p]
     L.rma_db_bases.argtypes = [vp]
     L.rma_db_bases.restype = C.c_int64
     L.rma_scan.argtypes = [vp, vp, C.POINTER(i32p), i64p, C.c_char_p, C.c_size_t]
@@ -136,15 +151,22 @@ class Descriptor:
 class Database:
     """Sequences packed 2 bit + ambiguity mask, resident in HBM."""
 
-    def __init__(self, scanner: "Scanner", seqs: Sequence[bytes]):
+    def __init__(self, scanner: "Scanner", seqs: Optional[Sequence[bytes]] = None, pack: Optional["Pack"] = None,
+                 first: int = 0, count: Optional[int] = None):
         L = lib()
         self.scanner = scanner
-        self.n_seqs = len(seqs)
-        arr = _cstr_array(seqs)
-        lens = (C.c_int32 * max(len(seqs), 1))(*[len(s) for s in seqs])
         h = C.c_void_p()
         err = C.create_string_buffer(_ERRLEN)
-        _check(L.rma_db_create(scanner._h, arr, lens, len(seqs), C.byref(h), err, _ERRLEN), err)
+        if pack is not None:
+            # entries [first, first+count) of a packed database, uploaded as they are
+            count = pack.count - first if count is None else count
+            self.n_seqs = count
+            _check(L.rma_db_create_packed(scanner._h, pack._h, first, count, C.byref(h), err, _ERRLEN), err)
+        else:
+            self.n_seqs = len(seqs)
+            arr = _cstr_array(seqs)
+            lens = (C.c_int32 * max(len(seqs), 1))(*[len(s) for s in seqs])
+            _check(L.rma_db_create(scanner._h, arr, lens, len(seqs), C.byref(h), err, _ERRLEN), err)
         self._h = h
         self.bases = L.rma_db_bases(h)
 
@@ -173,6 +195,9 @@ class Scanner:
 
     def database(self, seqs: Sequence[bytes]) -> Database:
         return Database(self, seqs)
+
+    def database_from_pack(self, pack: "Pack", first: int = 0, count: Optional[int] = None) -> Database:
+        return Database(self, pack=pack, first=first, count=count)
 
     def scan(self, db: Database) -> np.ndarray:
         """All candidates of db in reference order: int32 array [n, hit_stride]."""
@@ -264,6 +289,52 @@ def read_fasta(path: str) -> List[Tuple[bytes, bytes, bytes]]:
         if sid is not None:
             recs.append((sid, sdef, b"".join(chunks)))
     return recs
+
+
+class Pack:
+    """A packed database on disk (rma_pack_*): what the readers deliver, in the
+    layout the scanner keeps in HBM."""
+
+    def __init__(self, path: str):
+        L = lib()
+        h = C.c_void_p()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_pack_open(path.encode(), C.byref(h), err, _ERRLEN), err)
+        self._h = h
+        self.count = int(L.rma_pack_count(h))
+        self.bases = int(L.rma_pack_bases(h))
+
+    @staticmethod
+    def write(path: str, records: Sequence[Tuple[bytes, bytes, bytes]]) -> None:
+        """records: (sid, sdef, seq) as read_fasta() returns them."""
+        L = lib()
+        n = len(records)
+        sids = _cstr_array([r[0] for r in records])
+        sdefs = _cstr_array([r[1] for r in records])
+        seqs = _cstr_array([r[2] for r in records])
+        slens = (C.c_int32 * max(n, 1))(*[len(r[2]) for r in records])
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_pack_write(path.encode(), sids, sdefs, seqs, slens, n, err, _ERRLEN), err)
+
+    def record(self, i: int) -> Tuple[bytes, bytes, bytes]:
+        L = lib()
+        n = int(L.rma_pack_slen(self._h, i))
+        if n < 0:
+            raise IndexError(i)
+        buf = C.create_string_buffer(n + 1)
+        L.rma_pack_seq(self._h, i, buf)
+        return (C.string_at(L.rma_pack_sid(self._h, i)), C.string_at(L.rma_pack_sdef(self._h, i)), buf.raw[:n])
+
+    def close(self) -> None:
+        if self._h:
+            lib().rma_pack_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def synthetic_records(k: int, length: int = 1_000_000, seed: int = 20240601) -> List[bytes]:

@@ -132,3 +132,77 @@ extern "C" int rma_replay_close( rma_replay_t *rp, char *err, size_t errlen )
 	delete rp;
 	return rv;
 }
+
+// ---------------------------------------------------------------- packed database
+#include "rm_pack.h"
+
+struct rma_pack {
+	rma::PackFile	pf;
+};
+
+extern "C" int rma_pack_write( const char *path, const char *const *sids, const char *const *sdefs,
+	const char *const *seqs, const int32_t *slens, int32_t n, char *err, size_t errlen )
+{
+	rma::PackFile	pf;
+	rma::SeqRecord	rec;
+	for( int i = 0; i < n; i++ ){
+		rec.sid = sids && sids[ i ] ? sids[ i ] : "";
+		rec.sdef = sdefs && sdefs[ i ] ? sdefs[ i ] : "";
+		rec.seq.assign( seqs[ i ], size_t( slens[ i ] < 0 ? 0 : slens[ i ] ) );
+		for( char &c : rec.seq ){		// what the readers do, dbutil.c:112-113
+			c = char( tolower( ( unsigned char )c ) );
+			if( c == 'u' )
+				c = 't';
+		}
+		pf.add( rec );
+	}
+	std::string	e;
+	if( !pf.save( path, e ) )
+		return set_err( err, errlen, e.c_str() );
+	return 0;
+}
+
+extern "C" int rma_pack_open( const char *path, rma_pack_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	rma_pack	*pk = new rma_pack;
+	std::string	e;
+	if( !pk->pf.load( path, e ) ){
+		delete pk;
+		return set_err( err, errlen, e.c_str() );
+	}
+	*out = pk;
+	return 0;
+}
+
+extern "C" void rma_pack_close( rma_pack_t *pk ) { delete pk; }
+extern "C" int32_t rma_pack_count( const rma_pack_t *pk ) { return pk->pf.count(); }
+extern "C" int64_t rma_pack_bases( const rma_pack_t *pk ) { return pk->pf.total_bases; }
+extern "C" const char *rma_pack_sid( const rma_pack_t *pk, int32_t i )
+{
+	return i >= 0 && i < pk->pf.count() ? pk->pf.sid( i ) : nullptr;
+}
+extern "C" const char *rma_pack_sdef( const rma_pack_t *pk, int32_t i )
+{
+	return i >= 0 && i < pk->pf.count() ? pk->pf.sdef( i ) : nullptr;
+}
+extern "C" int32_t rma_pack_slen( const rma_pack_t *pk, int32_t i )
+{
+	return i >= 0 && i < pk->pf.count() ? pk->pf.slen[ i ] : -1;
+}
+extern "C" int rma_pack_seq( const rma_pack_t *pk, int32_t i, char *buf )
+{
+	if( i < 0 || i >= pk->pf.count() )
+		return 1;
+	std::string	s = pk->pf.unpack( i );
+	memcpy( buf, s.c_str(), s.size() + 1 );
+	return 0;
+}
+
+// for rm_scan_hip.hip
+const rma::PackFile *rma_pack_file( const rma_pack_t *pk ) { return &pk->pf; }
+const rma_pack_t *rma_pack_wrap( const rma::PackFile *pf )
+{
+	static_assert( offsetof( rma_pack, pf ) == 0, "rma_pack wraps exactly one PackFile" );
+	return reinterpret_cast<const rma_pack_t *>( pf );
+}

@@ -1,6 +1,7 @@
 // rm_driver.cpp -- see rm_driver.h.
 #include "rm_driver.h"
 #include "rm_score.h"
+#include "rm_pack.h"
 #include <cstring>
 
 namespace rma {
@@ -126,8 +127,73 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		batch.clear();
 		in_batch = 0;
 	};
+	// A packed database (rm_pack.h) takes the place of a text file: same entries, same order.
+	auto scan_pack = [&]( const std::string &path ){
+		PackFile	pk;
+		std::string	perr;
+		if( !pk.load( path, perr ) )
+			fail( "%s", perr.c_str() );
+		int	first = 0;
+		while( first < pk.count() ){
+			int	count = 0;
+			int64_t	bases = 0;
+			while( first + count < pk.count() && ( count == 0 || bases < batch_bases ) ){
+				bases += pk.slen[ first + count ];
+				count++;
+			}
+			for( int i = 0; i < count; i++ ){
+				ecnt++;
+				if( show_progress > 0 && ecnt % show_progress == 0 )
+					fprintf( stderr, "%s: %7d: %s\n", d.args.argv0.c_str(), ecnt, pk.sid( first + i ) );
+			}
+			st.n_seqs += count;
+			st.n_bases += bases;
+			const int32_t	*hits = nullptr;
+			int64_t	n_hits = 0;
+			err[ 0 ] = '\0';
+			std::vector<SeqRecord>	recs;
+			recs.resize( size_t( count ) );
+			if( be.scan_packed != nullptr ){
+				if( be.scan_packed( be.self, &pk, first, count, &hits, &n_hits, err, sizeof( err ) ) )
+					fail( "scan failed: %s", err );
+			}else{
+				std::vector<const char *>	seqs;
+				std::vector<int32_t>	slens;
+				for( int i = 0; i < count; i++ ){
+					recs[ i ].seq = pk.unpack( first + i );
+					seqs.push_back( recs[ i ].seq.c_str() );
+					slens.push_back( pk.slen[ first + i ] );
+				}
+				if( be.scan( be.self, seqs.data(), slens.data(), count, &hits, &n_hits, err, sizeof( err ) ) )
+					fail( "scan failed: %s", err );
+			}
+			// text only for the entries that have candidates
+			const int	stride = rma_hit_stride( &prog );
+			for( int64_t h = 0; h < n_hits; h++ ){
+				const int	i = hits[ h * stride ];
+				if( i < 0 || i >= count )
+					fail( "scanner returned a hit for sequence %d of a batch of %d.", i, count );
+				SeqRecord	&r = recs[ i ];
+				if( r.sid.empty() ){
+					r.sid = pk.sid( first + i );
+					r.sdef = pk.sdef( first + i );
+					if( r.seq.empty() )
+						r.seq = pk.unpack( first + i );
+				}
+			}
+			rp.replay( recs, hits, n_hits, st );
+			first += count;
+		}
+	};
 	for( size_t f = 0; f < nfiles; f++ ){
 		FILE	*fp = stdin;
+		if( !use_stdin && PackFile::is_pack( d.args.dbfnames[ f ] ) ){
+			flush();
+			scan_pack( d.args.dbfnames[ f ] );
+			if( f + 1 < nfiles )
+				ecnt++;		// the EOF that switches files is counted, rnamot.c:160-168
+			continue;
+		}
 		if( !use_stdin ){
 			fp = fopen( d.args.dbfnames[ f ].c_str(), "r" );
 			if( fp == nullptr ){

@@ -13,10 +13,15 @@ namespace rma {
 // What the driver needs from a scanner: scan n sequences (both strands when
 // the program says so) and return hit records sorted by (seq,comp,szero,rank,order).
 // The product binary plugs the HIP scanner in here (rm_capi.cpp).
+struct PackFile;
 struct ScanBackend {
 	void	*self;
 	int	( *scan )( void *self, const char *const *seqs, const int32_t *slens, int n,
 			const int32_t **hits, int64_t *n_hits, char *err, size_t errlen );
+	// optional: scan entries [first, first+count) of a packed database (rm_pack.h) without
+	// going through text; hit records number the entries from 0 = first
+	int	( *scan_packed )( void *self, const PackFile *pk, int first, int count,
+			const int32_t **hits, int64_t *n_hits, char *err, size_t errlen ) = nullptr;
 };
 
 struct SearchStats {

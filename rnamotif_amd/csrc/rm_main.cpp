@@ -3,6 +3,10 @@
 // is reached through the C ABI only; there is no CPU search path in this binary.
 #include "rm_cli.h"
 #include "rnamotif_amd.h"
+#include "rm_pack.h"
+
+// rm_capi.cpp: rma_pack is a struct whose only member is the PackFile
+const rma_pack_t *rma_pack_wrap( const rma::PackFile *pf );
 #include <cstdlib>
 
 namespace {
@@ -25,6 +29,20 @@ int hip_scan( void *self, const char *const *seqs, const int32_t *slens, int n,
 	return rma_scan( hb->sc, hb->db, hits, n_hits, err, errlen );
 }
 
+int hip_scan_packed( void *self, const rma::PackFile *pk, int first, int count,
+	const int32_t **hits, int64_t *n_hits, char *err, size_t errlen )
+{
+	HipBackend	*hb = ( HipBackend * )self;
+	if( hb->db != nullptr ){
+		rma_db_destroy( hb->db );
+		hb->db = nullptr;
+	}
+	// the driver holds a PackFile; the ABI wants the handle that wraps one
+	if( rma_db_create_packed( hb->sc, rma_pack_wrap( pk ), first, count, &hb->db, err, errlen ) )
+		return 1;
+	return rma_scan( hb->sc, hb->db, hits, n_hits, err, errlen );
+}
+
 rma::ScanBackend make_hip( const rma_program_t *prog, const rma_efndata_t *efn )
 {
 	HipBackend	*hb = new HipBackend;
@@ -32,7 +50,7 @@ rma::ScanBackend make_hip( const rma_program_t *prog, const rma_efndata_t *efn )
 	const char	*dv = getenv( "RNAMOTIF_DEVICE" );
 	if( rma_scanner_create( prog, efn, dv ? atoi( dv ) : 0, &hb->sc, err, sizeof( err ) ) )
 		rma::fail( "%s", err );
-	return rma::ScanBackend{ hb, hip_scan };
+	return rma::ScanBackend{ hb, hip_scan, hip_scan_packed };
 }
 
 }	// namespace

@@ -1,0 +1,46 @@
+// rm_pack.h -- persistent packed database: the 2-bit + ambiguity-mask layout the
+// scanner keeps in HBM (rm_fasta.h), written to disk once so that repeat scans skip
+// reading and packing the text.  Everything print_match()
+// needs survives: entry names, definition lines and the letters at ambiguous
+// positions, so the original (lower-cased, u->t) sequence text can be rebuilt for
+// any entry -- FN_fgetseq's output, /root/reference/src/dbutil.c:42-128.
+//
+// File layout (little endian):
+//   char     magic[8]  "RMAPACK1"
+//   int64    n_seq, n_code_words, n_mask_words, n_exc, n_text
+//   int32    slen[n_seq]
+//   int64    base_off[n_seq]        offset in bases, multiple of 32
+//   int64    exc_off[n_seq]         index of the entry's first letter in exc[]
+//   uint32   codes[n_code_words]    16 bases per word
+//   uint32   amask[n_mask_words]    32 bases per word
+//   char     exc[n_exc]             letters at the masked positions, in order
+//   char     text[n_text]           sid\0sdef\0 per entry
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "rm_fasta.h"
+
+namespace rma {
+
+struct PackFile {
+	std::vector<int32_t>	slen;
+	std::vector<int64_t>	base_off, exc_off;
+	std::vector<uint32_t>	codes, amask;
+	std::vector<char>	exc, text;
+	std::vector<int64_t>	sid_off, sdef_off;	// into text (built on load)
+	int64_t	total_bases = 0;
+
+	int	count() const { return int( slen.size() ); }
+	const char	*sid( int i ) const { return text.data() + sid_off[ i ]; }
+	const char	*sdef( int i ) const { return text.data() + sdef_off[ i ]; }
+	void	add( const SeqRecord &rec );
+	std::string	unpack( int i ) const;		// the entry's sequence text
+	bool	save( const std::string &path, std::string &err ) const;
+	bool	load( const std::string &path, std::string &err );
+	static bool	is_pack( const std::string &path );
+private:
+	void	index_text();
+};
+
+}	// namespace rma

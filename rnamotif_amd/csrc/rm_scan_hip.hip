@@ -29,6 +29,7 @@
 #include "rm_scan_core.h"
 #include "rm_efn_core.h"
 #include "rm_fasta.h"
+#include "rm_pack.h"
 #include "rnamotif_amd.h"
 
 // ---------------------------------------------------------------- device views
@@ -646,6 +647,45 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 	delete sc;
 }
 
+// Upload n packed entries: codes/amask hold n_code_words/n_mask_words words, base_off[] are
+// offsets in bases (multiples of 32) relative to the first word of the arrays.
+static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_words, const uint32_t *amask,
+	size_t n_mask_words, const int64_t *base_off, const int32_t *slen, int32_t n, rma_db_t **out, char *err, size_t errlen )
+{
+	rma_db	*db = new rma_db;
+	db->sc = sc;
+	db->n_seq = n;
+	db->total_bases = 0;
+	db->strands = sc->prog.chk_both_strs ? 2 : 1;
+	std::vector<int64_t>	tile_start( size_t( n ) + 1, 0 );
+	const int	T = sc->tile_t;
+	for( int i = 0; i < n; i++ ){
+		db->total_bases += slen[ i ];
+		int64_t	nsz = int64_t( slen[ i ] ) - sc->prog.dminlen + 1;
+		int64_t	nt = nsz > 0 ? ( nsz + T - 1 ) / T : 0;
+		tile_start[ i + 1 ] = tile_start[ i ] + nt * db->strands;
+	}
+	db->n_tiles = tile_start[ n ];
+	HIPCHK( hipSetDevice( sc->device ) );
+	size_t	nc = std::max<size_t>( n_code_words, 1 ), na = std::max<size_t>( n_mask_words, 1 );
+	HIPCHK( hipMalloc( &db->d_codes, nc * sizeof( uint32_t ) ) );
+	HIPCHK( hipMalloc( &db->d_amask, na * sizeof( uint32_t ) ) );
+	HIPCHK( hipMalloc( &db->d_base_off, std::max<size_t>( n, 1 ) * sizeof( int64_t ) ) );
+	HIPCHK( hipMalloc( &db->d_slen, std::max<size_t>( n, 1 ) * sizeof( int32_t ) ) );
+	HIPCHK( hipMalloc( &db->d_tile_start, ( size_t( n ) + 1 ) * sizeof( int64_t ) ) );
+	if( n_code_words > 0 ){
+		HIPCHK( hipMemcpy( db->d_codes, codes, n_code_words * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
+		HIPCHK( hipMemcpy( db->d_amask, amask, n_mask_words * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
+	}
+	if( n > 0 ){
+		HIPCHK( hipMemcpy( db->d_base_off, base_off, size_t( n ) * sizeof( int64_t ), hipMemcpyHostToDevice ) );
+		HIPCHK( hipMemcpy( db->d_slen, slen, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
+	}
+	HIPCHK( hipMemcpy( db->d_tile_start, tile_start.data(), tile_start.size() * sizeof( int64_t ), hipMemcpyHostToDevice ) );
+	*out = db;
+	return 0;
+}
+
 extern "C" int rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
 	rma_db_t **out, char *err, size_t errlen )
 {
@@ -653,37 +693,32 @@ extern "C" int rma_db_create( rma_scanner_t *sc, const char *const *seqs, const 
 	rma::PackedDb	pk;
 	for( int i = 0; i < n; i++ )
 		pk.add( seqs[ i ], slens[ i ] < 0 ? 0 : slens[ i ] );
-	rma_db	*db = new rma_db;
-	db->sc = sc;
-	db->n_seq = n;
-	db->total_bases = pk.total_bases;
-	db->strands = sc->prog.chk_both_strs ? 2 : 1;
-	std::vector<int64_t>	tile_start( size_t( n ) + 1, 0 );
-	const int	T = sc->tile_t;
-	for( int i = 0; i < n; i++ ){
-		int64_t	nsz = int64_t( pk.slen[ i ] ) - sc->prog.dminlen + 1;
-		int64_t	nt = nsz > 0 ? ( nsz + T - 1 ) / T : 0;
-		tile_start[ i + 1 ] = tile_start[ i ] + nt * db->strands;
+	return db_upload( sc, pk.codes.data(), pk.codes.size(), pk.amask.data(), pk.amask.size(),
+		pk.base_off.data(), pk.slen.data(), n, out, err, errlen );
+}
+
+const rma::PackFile *rma_pack_file( const rma_pack_t *pk );	// rm_capi.cpp
+
+extern "C" int rma_db_create_packed( rma_scanner_t *sc, const rma_pack_t *pack, int32_t first, int32_t count,
+	rma_db_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	const rma::PackFile	&pf = *rma_pack_file( pack );
+	if( first < 0 || count < 0 || first + count > pf.count() ){
+		snprintf( err, errlen, "entries [%d, %d) are outside the packed database (%d entries)", first, first + count, pf.count() );
+		return 1;
 	}
-	db->n_tiles = tile_start[ n ];
-	HIPCHK( hipSetDevice( sc->device ) );
-	size_t	nc = std::max<size_t>( pk.codes.size(), 1 ), na = std::max<size_t>( pk.amask.size(), 1 );
-	HIPCHK( hipMalloc( &db->d_codes, nc * sizeof( uint32_t ) ) );
-	HIPCHK( hipMalloc( &db->d_amask, na * sizeof( uint32_t ) ) );
-	HIPCHK( hipMalloc( &db->d_base_off, std::max<size_t>( n, 1 ) * sizeof( int64_t ) ) );
-	HIPCHK( hipMalloc( &db->d_slen, std::max<size_t>( n, 1 ) * sizeof( int32_t ) ) );
-	HIPCHK( hipMalloc( &db->d_tile_start, ( size_t( n ) + 1 ) * sizeof( int64_t ) ) );
-	if( !pk.codes.empty() ){
-		HIPCHK( hipMemcpy( db->d_codes, pk.codes.data(), pk.codes.size() * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
-		HIPCHK( hipMemcpy( db->d_amask, pk.amask.data(), pk.amask.size() * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
-	}
-	if( n > 0 ){
-		HIPCHK( hipMemcpy( db->d_base_off, pk.base_off.data(), size_t( n ) * sizeof( int64_t ), hipMemcpyHostToDevice ) );
-		HIPCHK( hipMemcpy( db->d_slen, pk.slen.data(), size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
-	}
-	HIPCHK( hipMemcpy( db->d_tile_start, tile_start.data(), tile_start.size() * sizeof( int64_t ), hipMemcpyHostToDevice ) );
-	*out = db;
-	return 0;
+	if( count == 0 )
+		return db_upload( sc, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, out, err, errlen );
+	const int64_t	b0 = pf.base_off[ first ];
+	const int	last = first + count - 1;
+	const int64_t	b1 = pf.base_off[ last ] + ( ( int64_t( pf.slen[ last ] ) + 31 ) / 32 ) * 32;
+	std::vector<int64_t>	rel;
+	rel.resize( size_t( count ) );
+	for( int i = 0; i < count; i++ )
+		rel[ i ] = pf.base_off[ first + i ] - b0;
+	return db_upload( sc, pf.codes.data() + b0 / 16, size_t( ( b1 - b0 ) / 16 ), pf.amask.data() + b0 / 32,
+		size_t( ( b1 - b0 ) / 32 ), rel.data(), pf.slen.data() + first, count, out, err, errlen );
 }
 
 extern "C" void rma_db_destroy( rma_db_t *db )
