@@ -280,6 +280,26 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			auto	win = [ & ]( int szero, int top, int r0, int lo ) -> unsigned long long {
 				unsigned long long	c1 = 0, c2 = 0, c3 = 0, c4 = 0, first = 0;	// >= 1/2/3/4 mispairs
 				const int	w0 = top - r0 - 63;
+				if( lim == 0 ){
+					// no mispair allowed: a plain AND of the shifted rows, and done as
+					// soon as no end position is left
+					unsigned long long	W = ~0ull;
+					for( int h = 0; h < hl0 && W; h++ ){
+						const int	qq = w0 - h - p_lo + 64;
+						unsigned long long	ph = 0;
+						if( qq >= 0 ){
+							const unsigned long long	*row = pb + rmd_code( sq, szero + h ) * pb_words;
+							const int	wi = qq >> 6, sh = qq & 63;
+							const unsigned long long	a0 = row[ wi ], a1 = row[ wi + 1 ];
+							ph = sh ? ( a0 >> sh ) | ( a1 << ( 64 - sh ) ) : a0;
+						}
+						W &= ph;
+					}
+					const int	imin = lo - w0;
+					if( imin > 0 )
+						W = imin >= 64 ? 0 : W & ( ~0ull << imin );
+					return W;
+				}
 				for( int h = 0; h < hl0; h++ ){
 					const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector
 					unsigned long long	ph = 0;
