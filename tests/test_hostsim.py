@@ -16,7 +16,7 @@ def hostsim():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "hostsim", "hostsim_check.cpp")]
     srcs += [os.path.join(H, f) for f in ("rm_regex.cpp", "rm_compile.cpp", "rm_parse.cpp", "rm_score.cpp",
-                                          "rm_efndata.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp",
+                                          "rm_efndata.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp", "rm_dump.cpp", "rm_pack.cpp",
                                           "rm_dev_program.cpp")]
     srcs += [os.path.join(ROOT, "oracle", f) for f in ("rm_oracle_scan.c", "rm_oracle_efn.c")]
     newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(H, "rm_scan_core.h")])
