@@ -59,6 +59,13 @@ void	rma_scanner_destroy( rma_scanner_t *sc );
  * 2 bits + 1 ambiguity bit per base and uploaded; the host text is not kept. */
 int	rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
 		rma_db_t **out, char *err, size_t errlen );
+/* The same, answering only for start positions pos_lo[i] <= szero < pos_hi[i] of each strand
+ * of entry i (RM_find_motif's szero, find_motif.c:184-205): a long entry can be searched by
+ * several devices, each holding the whole entry and a slice of its start positions; the union
+ * of the hit records, sorted by their first five words, is the whole entry's hit list. */
+int	rma_db_create_ranges( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens,
+		const int32_t *pos_lo, const int32_t *pos_hi, int32_t n,
+		rma_db_t **out, char *err, size_t errlen );
 void	rma_db_destroy( rma_db_t *db );
 int64_t	rma_db_bases( const rma_db_t *db );
 

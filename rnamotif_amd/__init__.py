@@ -64,6 +64,7 @@ def lib() -> C.CDLL:
     L.rma_scanner_destroy.argtypes = [vp]
     L.rma_db_create.argtypes = [vp, cpp, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_db_destroy.argtypes = [vp]
+    L.rma_db_create_ranges.argtypes = [vp, cpp, i32p, i32p, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_db_create_packed.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_pack_write.argtypes = [C.c_char_p, cpp, cpp, cpp, i32p, C.c_int32, C.c_char_p, C.c_size_t]
     L.rma_pack_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -152,7 +153,7 @@ class Database:
     """Sequences packed 2 bit + ambiguity mask, resident in HBM."""
 
     def __init__(self, scanner: "Scanner", seqs: Optional[Sequence[bytes]] = None, pack: Optional["Pack"] = None,
-                 first: int = 0, count: Optional[int] = None):
+                 first: int = 0, count: Optional[int] = None, ranges: Optional[Sequence[Tuple[int, int]]] = None):
         L = lib()
         self.scanner = scanner
         h = C.c_void_p()
@@ -166,7 +167,13 @@ class Database:
             self.n_seqs = len(seqs)
             arr = _cstr_array(seqs)
             lens = (C.c_int32 * max(len(seqs), 1))(*[len(s) for s in seqs])
-            _check(L.rma_db_create(scanner._h, arr, lens, len(seqs), C.byref(h), err, _ERRLEN), err)
+            if ranges is not None:
+                # only start positions lo <= szero < hi of each strand of entry i (rma_db_create_ranges)
+                lo = (C.c_int32 * max(len(seqs), 1))(*[int(r[0]) for r in ranges])
+                hi = (C.c_int32 * max(len(seqs), 1))(*[int(r[1]) for r in ranges])
+                _check(L.rma_db_create_ranges(scanner._h, arr, lens, lo, hi, len(seqs), C.byref(h), err, _ERRLEN), err)
+            else:
+                _check(L.rma_db_create(scanner._h, arr, lens, len(seqs), C.byref(h), err, _ERRLEN), err)
         self._h = h
         self.bases = L.rma_db_bases(h)
 
@@ -193,8 +200,8 @@ class Scanner:
         _check(L.rma_scanner_create(descr.program, descr.efndata, device, C.byref(h), err, _ERRLEN), err)
         self._h = h
 
-    def database(self, seqs: Sequence[bytes]) -> Database:
-        return Database(self, seqs)
+    def database(self, seqs: Sequence[bytes], ranges: Optional[Sequence[Tuple[int, int]]] = None) -> Database:
+        return Database(self, seqs, ranges=ranges)
 
     def database_from_pack(self, pack: "Pack", first: int = 0, count: Optional[int] = None) -> Database:
         return Database(self, pack=pack, first=first, count=count)

@@ -38,6 +38,7 @@ struct DbView {
 	const int64_t	*base_off;	// [n_seq]   first base of sequence s (multiple of 32)
 	const int32_t	*slen;		// [n_seq]
 	const int64_t	*tile_start;	// [n_seq+1] prefix sum of tiles over sequences
+	const int32_t	*pos_lo, *pos_hi;	// [n_seq] or null: only start positions lo <= szero < hi (each strand)
 	int32_t	n_seq, strands, tile_t;
 	int64_t	n_tiles;
 };
@@ -179,7 +180,9 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		const int	local = int( t - db.tile_start[ seq ] );
 		const int	per_strand = int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands );
 		const int	comp = local / per_strand;
-		const int	z0 = ( local % per_strand ) * T;
+		const int	pos_lo = db.pos_lo ? db.pos_lo[ seq ] : 0;
+		const int	pos_hi = db.pos_hi ? db.pos_hi[ seq ] : 0x7fffffff;
+		const int	z0 = pos_lo + ( local % per_strand ) * T;
 
 		// decode the bases this tile can touch: [ z0 - lm, z0 + T + w - 1 + rm )
 		const int	p_lo = z0 - lm;
@@ -328,7 +331,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 			for( int j = 0; j < T; j += BLOCK ){
 				const int	rel = j + tid;
 				const int	szero = z0 + rel;
-				bool	valid = rel < T && szero <= slen - P->dminlen;
+				bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
 				if( valid )
 					LIT_OK( szero, valid );
 				int	hi = 0, lo = 1;
@@ -371,7 +374,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		for( int j = 0; j < T; j += BLOCK ){
 			const int	rel = j + tid;
 			const int	szero = z0 + rel;
-			bool	valid = rel < T && szero <= slen - P->dminlen;
+			bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
 			if( valid )
 				LIT_OK( szero, valid );
 			int	hi = 0, lo = 1;
@@ -540,7 +543,7 @@ struct rma_db {
 	rma_scanner	*sc;
 	uint32_t	*d_codes = nullptr, *d_amask = nullptr;
 	int64_t	*d_base_off = nullptr, *d_tile_start = nullptr;
-	int32_t	*d_slen = nullptr;
+	int32_t	*d_slen = nullptr, *d_pos_lo = nullptr, *d_pos_hi = nullptr;
 	int32_t	n_seq = 0;
 	int64_t	n_tiles = 0, total_bases = 0;
 	int	strands = 2;
@@ -670,8 +673,15 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 // Upload n packed entries: codes/amask hold n_code_words/n_mask_words words, base_off[] are
 // offsets in bases (multiples of 32) relative to the first word of the arrays.
 static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_words, const uint32_t *amask,
-	size_t n_mask_words, const int64_t *base_off, const int32_t *slen, int32_t n, rma_db_t **out, char *err, size_t errlen )
+	size_t n_mask_words, const int64_t *base_off, const int32_t *slen, int32_t n, rma_db_t **out, char *err, size_t errlen,
+	const int32_t *pos_lo = nullptr, const int32_t *pos_hi = nullptr )
 {
+	if( pos_lo != nullptr )
+		for( int i = 0; i < n; i++ )
+			if( pos_lo[ i ] < 0 || pos_hi[ i ] < pos_lo[ i ] ){
+				snprintf( err, errlen, "entry %d: start positions [%d, %d) are not a range", i, pos_lo[ i ], pos_hi[ i ] );
+				return 1;
+			}
 	rma_db	*db = new rma_db;
 	db->sc = sc;
 	db->n_seq = n;
@@ -680,8 +690,13 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 	std::vector<int64_t>	tile_start( size_t( n ) + 1, 0 );
 	const int	T = sc->tile_t;
 	for( int i = 0; i < n; i++ ){
-		db->total_bases += slen[ i ];
-		int64_t	nsz = int64_t( slen[ i ] ) - sc->prog.dminlen + 1;
+		int64_t	nsz = int64_t( slen[ i ] ) - sc->prog.dminlen + 1;	// start positions of a strand
+		if( pos_lo != nullptr ){
+			// this database answers for a slice of the entry's start positions only
+			db->total_bases += std::max<int64_t>( 0, std::min<int64_t>( pos_hi[ i ], slen[ i ] ) - pos_lo[ i ] );
+			nsz = std::min<int64_t>( nsz, pos_hi[ i ] ) - pos_lo[ i ];
+		}else
+			db->total_bases += slen[ i ];
 		int64_t	nt = nsz > 0 ? ( nsz + T - 1 ) / T : 0;
 		tile_start[ i + 1 ] = tile_start[ i ] + nt * db->strands;
 	}
@@ -702,8 +717,25 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 		HIPCHK( hipMemcpy( db->d_slen, slen, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
 	}
 	HIPCHK( hipMemcpy( db->d_tile_start, tile_start.data(), tile_start.size() * sizeof( int64_t ), hipMemcpyHostToDevice ) );
+	if( pos_lo != nullptr && n > 0 ){
+		HIPCHK( hipMalloc( &db->d_pos_lo, size_t( n ) * sizeof( int32_t ) ) );
+		HIPCHK( hipMalloc( &db->d_pos_hi, size_t( n ) * sizeof( int32_t ) ) );
+		HIPCHK( hipMemcpy( db->d_pos_lo, pos_lo, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
+		HIPCHK( hipMemcpy( db->d_pos_hi, pos_hi, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
+	}
 	*out = db;
 	return 0;
+}
+
+extern "C" int rma_db_create_ranges( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens,
+	const int32_t *pos_lo, const int32_t *pos_hi, int32_t n, rma_db_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	rma::PackedDb	pk;
+	for( int i = 0; i < n; i++ )
+		pk.add( seqs[ i ], slens[ i ] < 0 ? 0 : slens[ i ] );
+	return db_upload( sc, pk.codes.data(), pk.codes.size(), pk.amask.data(), pk.amask.size(),
+		pk.base_off.data(), pk.slen.data(), n, out, err, errlen, pos_lo, pos_hi );
 }
 
 extern "C" int rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
@@ -751,6 +783,8 @@ extern "C" void rma_db_destroy( rma_db_t *db )
 	( void )hipFree( db->d_base_off );
 	( void )hipFree( db->d_slen );
 	( void )hipFree( db->d_tile_start );
+	( void )hipFree( db->d_pos_lo );
+	( void )hipFree( db->d_pos_hi );
 	delete db;
 }
 
@@ -764,6 +798,8 @@ static DbView view_of( const rma_scanner *sc, const rma_db *db )
 	v.base_off = db->d_base_off;
 	v.slen = db->d_slen;
 	v.tile_start = db->d_tile_start;
+	v.pos_lo = db->d_pos_lo;
+	v.pos_hi = db->d_pos_hi;
 	v.n_seq = db->n_seq;
 	v.strands = db->strands;
 	v.tile_t = sc->tile_t;

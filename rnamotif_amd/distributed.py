@@ -29,6 +29,37 @@ def partition_by_bases(lengths: Sequence[int], world: int) -> List[List[int]]:
     return parts
 
 
+def partition_ranges(lengths: Sequence[int], world: int, max_chunk: int = 0) -> List[List[Tuple[int, int, int]]]:
+    """Like partition_by_bases(), but entries longer than `max_chunk` start
+    positions (default: a world-th of the database) are cut into slices of
+    start positions that different ranks search (the C ABI
+    takes them as rma_db_create_ranges()).  Returns per rank a list of
+    (entry index, lo, hi), sorted by entry and position; every rank that holds a
+    slice holds the whole entry's text, so nothing overlaps and nothing is lost
+    at the cuts."""
+    total = sum(lengths)
+    if max_chunk <= 0:
+        max_chunk = max(1, -(-total // max(world, 1)))
+    work: List[Tuple[int, int, int]] = []
+    for i, n in enumerate(lengths):
+        if n <= max_chunk:
+            work.append((i, 0, max(n, 0)))
+        else:
+            k = -(-n // max_chunk)
+            step = -(-n // k)
+            for lo in range(0, n, step):
+                work.append((i, lo, min(n, lo + step)))
+    loads = [0] * world
+    parts: List[List[Tuple[int, int, int]]] = [[] for _ in range(world)]
+    for w in sorted(work, key=lambda w: (-(w[2] - w[1]), w[0], w[1])):
+        r = min(range(world), key=lambda r: (loads[r], r))
+        parts[r].append(w)
+        loads[r] += w[2] - w[1]
+    for p in parts:
+        p.sort()
+    return parts
+
+
 def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int, device=None) -> np.ndarray:
     """Gather int32 hit records [n, stride] from every rank to rank 0.
 

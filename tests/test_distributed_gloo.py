@@ -66,3 +66,65 @@ def test_partition_balances_and_keeps_order():
     loads = [sum(lens[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= max(lens)
     assert all(p == sorted(p) for p in parts)
+
+
+def test_partition_ranges_covers_every_start_position_once():
+    from rnamotif_amd.distributed import partition_ranges
+    lens = [100_000, 10, 0, 35_000, 7]
+    parts = partition_ranges(lens, 4)
+    cover = {i: [] for i in range(len(lens))}
+    for p in parts:
+        assert p == sorted(p)
+        for i, lo, hi in p:
+            cover[i].append((lo, hi))
+    for i, n in enumerate(lens):
+        spans = sorted(cover[i])
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    loads = [sum(hi - lo for _, lo, hi in p) for p in parts]
+    assert max(loads) <= 1.3 * sum(lens) / 4
+
+
+RANGE_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import rnamotif_amd as R
+from rnamotif_amd.distributed import partition_ranges, gather_hits
+from oracle_binding import oracle_scan
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+d = R.Descriptor(["-descr", os.path.join(sys.argv[1], "tests", "golden", "test", "sprintf.descr")])
+rng = np.random.default_rng(5)
+lut = np.frombuffer(b"acgt", dtype=np.uint8)
+seqs = [lut[rng.integers(0, 4, size=int(n))].tobytes() for n in (90000, 700, 20000)]
+mine = partition_ranges([len(s) for s in seqs], world, max_chunk=25000)[rank]
+# the slice of the start positions this rank answers for (what rma_db_create_ranges() does on
+# the device): here the oracle scans the entry and the records outside the slice are dropped
+idx = sorted(set(w[0] for w in mine))
+h = oracle_scan(d, [seqs[i] for i in idx])
+keep = np.zeros(h.shape[0], dtype=bool)
+for i, lo, hi in mine:
+    keep |= (h[:, 0] == idx.index(i)) & (h[:, 2] >= lo) & (h[:, 2] < hi)
+allh = gather_hits(h[keep], idx, d.hit_stride)
+if rank == 0:
+    want = oracle_scan(d, seqs)
+    assert allh.shape == want.shape and np.array_equal(allh, want), (allh.shape, want.shape)
+    assert want.shape[0] > 0
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_range_sharding_world2(built, tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(RANGE_WORKER)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout.decode()[-4000:]

@@ -220,3 +220,25 @@ def test_syn10m_cli_hit_counts(built, workdir, tmp_path_factory, name):
     if name == "trna.efn.descr":
         first = [l for l in lines if l.startswith(b"syn")][0]
         assert b" ".join(first.split()) == b" ".join(SYN10M_FIRST_TRNA.split())
+
+
+def test_start_position_ranges(built, workdir):
+    """rma_db_create_ranges: slices of an entry's start positions searched separately (as
+    different GPUs would) add up to the whole entry's records, cut anywhere."""
+    import rnamotif_amd as R
+    rng = np.random.default_rng(21)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    seqs = [lut[rng.integers(0, 4, size=n)].tobytes() for n in (300_000, 50, 4_100)]
+    for name in ("trna.descr", "pk1.descr"):
+        d = _descr(workdir, name)
+        sc = R.Scanner(d)
+        whole = sc.scan(sc.database(seqs))
+        cuts = [0, 1, 2047, 2048, 2049, 77_777, 150_000, 299_950, 300_000]
+        parts = []
+        for lo, hi in zip(cuts, cuts[1:]):
+            parts.append(sc.scan(sc.database(seqs, ranges=[(lo, hi), (lo, hi), (lo, hi)])))
+        allh = np.concatenate(parts, axis=0)
+        allh = allh[np.lexsort(allh[:, :5].T[::-1])]
+        assert whole.shape[0] > 0 and np.array_equal(allh, whole), name
+        empty = sc.scan(sc.database(seqs, ranges=[(5, 5), (0, 0), (4_100, 9_000)]))
+        assert empty.shape[0] == 0
