@@ -128,3 +128,51 @@ def test_range_sharding_world2(built, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
                        env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert p.returncode == 0, p.stdout.decode()[-4000:]
+
+
+MRNAMOTIF_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+from rnamotif_amd import mrnamotif
+from oracle_binding import oracle_scan
+
+def cpu_scan(descr, seqs, ranges):
+    # stands in for Scanner.scan( database( seqs, ranges ) ) -- no GPU in this container
+    h = oracle_scan(descr, seqs)
+    keep = np.zeros(h.shape[0], dtype=bool)
+    for k, (lo, hi) in enumerate(ranges):
+        keep |= (h[:, 0] == k) & (h[:, 2] >= lo) & (h[:, 2] < hi)
+    return h[keep]
+
+os.chdir(sys.argv[2])
+mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], scan=cpu_scan, out_path=sys.argv[4])
+'''
+
+
+def test_mrnamotif_world2_prints_what_rnamotif_prints(built, workdir, gbrna, tmp_path):
+    """The multi-process command line (one rank per GPU on a node) over gloo with the oracle
+    standing in for the device scan: rank 0 prints byte for byte what the single-process
+    program prints, including one long entry cut between the ranks."""
+    import rnamotif_amd as R
+    recs = R.read_fasta(gbrna)[:300]
+    big = (b"joined", b"entries 300..899 as one", b"".join(r[2] for r in R.read_fasta(gbrna)[300:900]))
+    fa = tmp_path / "db.fastn"
+    fa.write_bytes(b"".join(b">" + s + b" " + d + b"\n" + q + b"\n" for s, d, q in recs + [big]))
+    env = dict(os.environ, OMP_NUM_THREADS="1", EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    want = subprocess.run([built["oracle_cli"], "-descr", "sprintf.descr", str(fa)], cwd=workdir, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert want.returncode == 0 and want.stdout.count(b"\n>") > 20
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(MRNAMOTIF_WORKER)
+    out = tmp_path / "out.txt"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, workdir,
+                        str(fa), str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
+    assert out.read_bytes() == want.stdout

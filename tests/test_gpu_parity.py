@@ -242,3 +242,16 @@ def test_start_position_ranges(built, workdir):
         assert whole.shape[0] > 0 and np.array_equal(allh, whole), name
         empty = sc.scan(sc.database(seqs, ranges=[(5, 5), (0, 0), (4_100, 9_000)]))
         assert empty.shape[0] == 0
+
+
+def test_mrnamotif_single_rank_equals_cli(built, workdir, gbrna, tmp_path):
+    """python -m rnamotif_amd.mrnamotif (the multi-GPU command line, here with one rank):
+    same bytes on stdout as bin/rnamotif."""
+    import sys
+    env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"), PYTHONPATH=ROOT)
+    want = _run_cli(built, workdir, ["-descr", "trna.efn.descr"])
+    p = subprocess.run([sys.executable, "-m", "rnamotif_amd.mrnamotif", "-descr", "trna.efn.descr", "gbrna.111.0.fastn"],
+                       cwd=workdir, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout == want
+    assert b"complete descr length: min/max = 63/95" in p.stderr
