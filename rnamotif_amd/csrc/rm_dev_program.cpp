@@ -368,6 +368,39 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		out->lmargin = std::max( 1, p->lctx.maxlen );
 	if( p->has_rctx && p->rctx.re >= 0 )
 		out->rmargin = std::max( 1, 2 * p->rctx.maxlen );
+	out->n_regexes = p->n_regexes;
+	out->n_rules = n_rules;
+	out->n_pairsets = n_ps;
+	out->off_regexes = int32_t( offsetof( rmd_program_t, regexes ) );
+	out->off_rules = int32_t( offsetof( rmd_program_t, rules ) );
+	out->off_pairsets = int32_t( offsetof( rmd_program_t, pairsets ) );
+	out->image_bytes = int32_t( sizeof( rmd_program_t ) );
 	return 0;
 #undef FAIL
+}
+
+size_t rmd_make_image( const rmd_program_t *full, void *img )
+{
+	char	*out = static_cast<char *>( img );
+	auto align = []( size_t v, size_t a ){ return ( v + a - 1 ) / a * a; };
+	// everything up to the last element in use ...
+	size_t	n = offsetof( rmd_program_t, elems ) + size_t( full->n_elems ) * sizeof( rmd_elem_t );
+	memcpy( out, full, n );
+	rmd_program_t	*hdr = reinterpret_cast<rmd_program_t *>( out );	// (only its leading members are valid)
+	// ... then the pools, most strictly aligned first
+	n = align( n, alignof( rmd_regex_t ) );
+	hdr->off_regexes = int32_t( n );
+	memcpy( out + n, full->regexes, size_t( full->n_regexes ) * sizeof( rmd_regex_t ) );
+	n += size_t( full->n_regexes ) * sizeof( rmd_regex_t );
+	n = align( n, alignof( rmd_rule_t ) );
+	hdr->off_rules = int32_t( n );
+	memcpy( out + n, full->rules, size_t( full->n_rules ) * sizeof( rmd_rule_t ) );
+	n += size_t( full->n_rules ) * sizeof( rmd_rule_t );
+	n = align( n, alignof( rmd_pairset_t ) );
+	hdr->off_pairsets = int32_t( n );
+	memcpy( out + n, full->pairsets, size_t( full->n_pairsets ) * sizeof( rmd_pairset_t ) );
+	n += size_t( full->n_pairsets ) * sizeof( rmd_pairset_t );
+	n = align( n, 16 );
+	hdr->image_bytes = int32_t( n );
+	return n;
 }

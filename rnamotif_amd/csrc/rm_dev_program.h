@@ -95,16 +95,43 @@ struct rmd_program_t {
 	// best-literal pre-filter (the role of the reference's -O, compile.c:3315): regex lit_re
 	// must occur with its first base at an offset in [lit_lo, lit_hi] from the start position
 	int32_t	lit_re, lit_lo, lit_hi;
+	// The three pools at the end are reached through byte offsets from the start of the
+	// program (rmd_pairsets() ...), so that the image a workgroup copies into LDS holds only
+	// what the descriptor uses: the members up to elems[ n_elems ], then the used regexes,
+	// rules and pair sets back to back (rmd_make_image()).  In this full struct the offsets
+	// point at the arrays below.
+	int32_t	n_regexes, n_rules, n_pairsets;
+	int32_t	off_regexes, off_rules, off_pairsets;
+	int32_t	image_bytes;
 	int8_t	searches[ RMD_MAX_ELEMS ];
-	rmd_elem_t	elems[ RMD_MAX_ELEMS ];
 	rmd_elem_t	lctx, rctx;
 	rmd_site_t	sites[ RMD_MAX_SITES ];
+	rma_efn_site_t	efn_sites[ RMD_MAX_EFN ];
+	rmd_elem_t	elems[ RMD_MAX_ELEMS ];
+	rmd_regex_t	regexes[ RMD_MAX_RE ];
 	rmd_rule_t	rules[ RMD_MAX_RULES ];
 	rmd_pairset_t	pairsets[ RMD_MAX_PS ];
-	rmd_regex_t	regexes[ RMD_MAX_RE ];
-	rma_efn_site_t	efn_sites[ RMD_MAX_EFN ];
 };
+
+#ifndef RMD_HD
+#define RMD_HD	inline
+#endif
+RMD_HD const rmd_regex_t *rmd_regexes( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rmd_regex_t *>( reinterpret_cast<const char *>( P ) + P->off_regexes );
+}
+RMD_HD const rmd_rule_t *rmd_rules( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rmd_rule_t *>( reinterpret_cast<const char *>( P ) + P->off_rules );
+}
+RMD_HD const rmd_pairset_t *rmd_pairsets( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rmd_pairset_t *>( reinterpret_cast<const char *>( P ) + P->off_pairsets );
+}
 
 // Build the device form; returns 0 or -1 with a message (descriptor outside
 // the device limits).  Implemented in rm_dev_program.cpp (host).
 int	rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t errlen );
+// The compact image of a built program (see rmd_program_t): image_bytes of it, 16-byte
+// multiple; img must hold sizeof( rmd_program_t ) bytes.
+size_t	rmd_make_image( const rmd_program_t *full, void *img );

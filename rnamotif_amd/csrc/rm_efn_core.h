@@ -460,7 +460,7 @@ struct rme_cand_t {
 			int	q1 = mlen( m ) - pq - 1;
 			int	ps = P->efn_usestdbp ? P->efn_stdbp : st.pairset;
 			int	b = sq->code( p ), b1 = sq->code( q1 + moff( m ) );
-			return ( ( P->pairsets[ ps ].mat2 >> ( b * 5 + b1 ) ) & 1 ) ? q1 + moff( m ) - off5 : -1;
+			return ( ( rmd_pairsets( P )[ ps ].mat2 >> ( b * 5 + b1 ) ) & 1 ) ? q1 + moff( m ) - off5 : -1;
 		}
 		return -1;
 	}

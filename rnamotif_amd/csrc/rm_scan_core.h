@@ -65,17 +65,17 @@ RMD_FN int rmd_code( const rmd_seq_t &s, int p ) { return s.sq[ p - s.sq0 ]; }
 
 RMD_FN int rmd_paired( const rmd_program_t *P, int ps, int b5, int b3 )		// RM_paired :1291
 {
-	return ( P->pairsets[ ps ].mat2 >> ( b5 * 5 + b3 ) ) & 1;
+	return ( rmd_pairsets( P )[ ps ].mat2 >> ( b5 * 5 + b3 ) ) & 1;
 }
 RMD_FN int rmd_triple( const rmd_program_t *P, int ps, int b1, int b2, int b3 )	// RM_triple :1304
 {
 	int	ix = ( b1 * 5 + b2 ) * 5 + b3;
-	return ( P->pairsets[ ps ].mat3[ ix >> 5 ] >> ( ix & 31 ) ) & 1;
+	return ( rmd_pairsets( P )[ ps ].mat3[ ix >> 5 ] >> ( ix & 31 ) ) & 1;
 }
 RMD_FN int rmd_quad( const rmd_program_t *P, int ps, int b1, int b2, int b3, int b4 )	// RM_quad :1318
 {
 	int	ix = ( ( b1 * 5 + b2 ) * 5 + b3 ) * 5 + b4;
-	return ( P->pairsets[ ps ].mat4[ ix >> 5 ] >> ( ix & 31 ) ) & 1;
+	return ( rmd_pairsets( P )[ ps ].mat4[ ix >> 5 ] >> ( ix & 31 ) ) & 1;
 }
 
 RMD_FN int rmd_popc64( uint64_t x )
@@ -158,7 +158,7 @@ RMD_COLD int rmd_re_mm_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off
 // chk_seq(), find_motif.c:1810
 RMD_FN int rmd_chk_seq( const rmd_program_t *P, const rmd_elem_t &e, const rmd_seq_t &sq, int off, int len, int *n_mm )
 {
-	const rmd_regex_t	&re = P->regexes[ e.re ];
+	const rmd_regex_t	&re = rmd_regexes( P )[ e.re ];
 	if( e.mismatch > 0 )
 		return rmd_re_mm_step( re, sq, off, len, e.mismatch, n_mm );
 	return rmd_re_step( re, sq, off, len );
@@ -171,7 +171,7 @@ RMD_FN int rmd_prefix_ok( const rmd_program_t *P, const rmd_elem_t &e, const rmd
 {
 	if( e.re < 0 || e.mismatch > 0 )
 		return 1;
-	const rmd_regex_t	&re = P->regexes[ e.re ];
+	const rmd_regex_t	&re = rmd_regexes( P )[ e.re ];
 	int	n = re.n_prefix < e.minlen ? re.n_prefix : e.minlen;
 	for( int i = 0; i < n; i++ )
 		if( !( ( re.accept[ rmd_code( sq, s5 + i ) ] >> i ) & 1 ) )
@@ -219,7 +219,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const rmd_seq_t &sq,
 			int	ok = 1;
 			if( !l_bpr && ( stp.ends & RMA_3PAIRED ) )
 				ok = 0;
-			else if( stp.pfrac && mpr > P->rules[ stp.rule ].pf_maxmpr[ hl ] )
+			else if( stp.pfrac && mpr > rmd_rules( P )[ stp.rule ].pf_maxmpr[ hl ] )
 				ok = 0;
 			else if( stp.re >= 0 && !rmd_chk_seq( P, stp, sq, s5, hl, &mm5 ) )
 				ok = 0;
@@ -292,7 +292,7 @@ RMD_COLD int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_se
 			return 0;
 		if( hl < stp.minlen || hl > stp.maxlen )
 			return 0;
-		if( stp.pfrac && mpr > P->rules[ stp.rule ].pf_maxmpr[ hl ] )
+		if( stp.pfrac && mpr > rmd_rules( P )[ stp.rule ].pf_maxmpr[ hl ] )
 			return 0;
 		int	mm;
 		if( stp.re >= 0 ){
@@ -321,7 +321,7 @@ RMD_COLD int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd
 	int d, int d1, int s1, int s2, int s3, int tlen, int *n_mpr )
 {
 	const rmd_elem_t	&stp = P->elems[ d ], &stp1 = P->elems[ d1 ];
-	int	mplim = P->rules[ stp.rule ].tq_mplim[ tlen ], mpr, l_pr;
+	int	mplim = rmd_rules( P )[ stp.rule ].tq_mplim[ tlen ], mpr, l_pr;
 	if( rmd_triple( P, stp.pairset, rmd_code( sq, s1 ), rmd_code( sq, s2 ), rmd_code( sq, s3 - tlen + 1 ) ) ){
 		mpr = 0;
 		l_pr = 1;
@@ -356,7 +356,7 @@ RMD_COLD int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_s
 	int d1, int d2, int s1, int s2, int s3, int s4, int qlen, int *n_mpr )
 {
 	const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
-	int	mplim = P->rules[ stp1.rule ].tq_mplim[ qlen ], mpr, l_pr;
+	int	mplim = rmd_rules( P )[ stp1.rule ].tq_mplim[ qlen ], mpr, l_pr;
 	if( rmd_quad( P, stp1.pairset, rmd_code( sq, s1 + qlen - 1 ), rmd_code( sq, s2 ), rmd_code( sq, s3 ), rmd_code( sq, s4 - qlen + 1 ) ) )
 		l_pr = 1;
 	else if( !( stp1.ends & RMA_5PAIRED ) )
@@ -409,7 +409,7 @@ RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const
 		l_bpr = 0;
 	}
 	for( ; ; ){
-		if( hl >= stp.minlen && ( l_bpr || !( stp.ends & RMA_3PAIRED ) ) && ( !stp.pfrac || mpr <= P->rules[ stp.rule ].pf_maxmpr[ hl ] ) )
+		if( hl >= stp.minlen && ( l_bpr || !( stp.ends & RMA_3PAIRED ) ) && ( !stp.pfrac || mpr <= rmd_rules( P )[ stp.rule ].pf_maxmpr[ hl ] ) )
 			return 1;
 		if( !( s3 - hl + 1 >= s3lim ) || hl >= stp.maxlen )
 			return 0;

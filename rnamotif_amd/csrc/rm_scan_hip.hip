@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 
+#define RMD_HD		__host__ __device__ inline
 #define RMD_FN		static __device__ inline
 #define RMD_COLD	static __device__ inline
 #define RMD_FN_MEMBER	__device__ inline
@@ -76,7 +77,6 @@ struct DevSink {
 	}
 };
 
-#define PROG_LDS_BYTES	( ( sizeof( rmd_program_t ) + 15 ) & ~size_t( 15 ) )
 #ifndef QCAP
 #define QCAP		1024		// work queue entries per workgroup
 #endif
@@ -104,17 +104,18 @@ struct LdsRecs {
 // instance at all (no scratch frames, fewer registers).
 template< int BLOCK, bool LEAN >
 __global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
-rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes, int dbg )
+rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
-	unsigned	*queue = reinterpret_cast<unsigned *>( smem + PROG_LDS_BYTES );
-	uint8_t	*tile = smem + PROG_LDS_BYTES + QCAP * sizeof( unsigned );
+	// gP is the compact image (rmd_make_image): prog_bytes of it, a multiple of 16
+	unsigned	*queue = reinterpret_cast<unsigned *>( smem + prog_bytes );
+	uint8_t	*tile = smem + prog_bytes + QCAP * sizeof( unsigned );
 	__shared__ long long	s_tile;
 	__shared__ int	s_seq, s_qn, s_qhead;
 	const int	tid = threadIdx.x;
 
-	for( unsigned i = tid; i < sizeof( rmd_program_t ) / 4; i += BLOCK )
+	for( unsigned i = tid; i < unsigned( prog_bytes ) / 4; i += BLOCK )
 		reinterpret_cast<uint32_t *>( P )[ i ] = reinterpret_cast<const uint32_t *>( gP )[ i ];
 	__syncthreads();
 
@@ -135,17 +136,17 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 	const bool	pk0 = e0.type == RMA_T_H5 && !e0.proper && e0.scope == 0 && !( dbg & 4 ) &&
 		e0.mplim <= 3 && e0.minlen >= 1;
 	const bool	bitpar = ( ( quick && !( dbg & 4 ) ) || pk0 ) && e0.mplim <= 3 && e0.minlen >= 1;
-	const unsigned	e0_mat2 = e0.pairset >= 0 ? P->pairsets[ e0.pairset ].mat2 : 0;
+	const unsigned	e0_mat2 = e0.pairset >= 0 ? rmd_pairsets( P )[ e0.pairset ].mat2 : 0;
 	const bool	e0_at_szero = e0.type == RMA_T_P5 || e0.type == RMA_T_T1 || e0.type == RMA_T_Q1 ||
 		( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
 	const int	pb_words = ( tile_bytes + 63 ) / 64 + 3;
-	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + PROG_LDS_BYTES + QCAP * sizeof( unsigned ) +
+	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + prog_bytes + QCAP * sizeof( unsigned ) +
 		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
 	unsigned long long	*occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
 	rmd_lrec_t	*lean = reinterpret_cast<rmd_lrec_t *>( occ + pb_words );
 	LdsRecs<BLOCK>	lr{ lean + threadIdx.x };
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
-	const int	lit_n = lit ? P->regexes[ P->lit_re ].n_states : 0;
+	const int	lit_n = lit ? rmd_regexes( P )[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
 	const bool	split_ranks = !quick && lit && n_rank > 1 && n_rank < 0xffff;
 
@@ -207,7 +208,7 @@ rma_search_kernel( const rmd_program_t *gP, DbView db, HitBuf hb, int tile_bytes
 		// necessary condition): occ has a bit for every tile position where the literal
 		// starts; a start position is searched only if one lies at an allowed offset.
 		if( lit ){
-			const rmd_regex_t	&lre = P->regexes[ P->lit_re ];
+			const rmd_regex_t	&lre = rmd_regexes( P )[ P->lit_re ];
 			const int	n_valid = p_to - p_lo;
 			for( int base = ( tid >> 6 ) * 64; base < pb_words * 64; base += BLOCK ){
 				const int	q = base + lane_id - 64;
@@ -527,7 +528,8 @@ struct rma_scanner {
 	int	device = 0;
 	hipStream_t	stream = nullptr;
 	hipEvent_t	ev[ 4 ] = { nullptr, nullptr, nullptr, nullptr };
-	rmd_program_t	*d_prog = nullptr;
+	rmd_program_t	*d_prog = nullptr;	// compact image, prog_bytes long
+	int	prog_bytes = 0;
 	int16_t	*d_t16 = nullptr;
 	int32_t	*d_tlkey = nullptr, *d_loginc = nullptr;
 	bool	have_efn = false;
@@ -595,6 +597,17 @@ extern "C" int rma_device_count( void )
 	return n;
 }
 
+// LDS of one search workgroup: program image | queue | tile | 6 bit vectors | lean records
+static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean )
+{
+	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
+	const size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	size_t	lds = size_t( prog_bytes ) + QCAP * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
+	if( lean )
+		lds += size_t( dp.n_searches ) * 256 * sizeof( rmd_lrec_t );
+	return lds;
+}
+
 extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_t *efn, int device,
 	rma_scanner_t **out, char *err, size_t errlen )
 {
@@ -624,8 +637,13 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	HIPCHK( hipStreamCreate( &sc->stream ) );
 	for( int i = 0; i < 4; i++ )
 		HIPCHK( hipEventCreate( &sc->ev[ i ] ) );
-	HIPCHK( hipMalloc( &sc->d_prog, sizeof( rmd_program_t ) ) );
-	HIPCHK( hipMemcpy( sc->d_prog, &sc->dprog, sizeof( rmd_program_t ), hipMemcpyHostToDevice ) );
+	{
+		// the device gets the compact image; sc->dprog stays the full struct for the host
+		std::vector<char>	img( sizeof( rmd_program_t ) );
+		sc->prog_bytes = int( rmd_make_image( &sc->dprog, img.data() ) );
+		HIPCHK( hipMalloc( &sc->d_prog, size_t( sc->prog_bytes ) ) );
+		HIPCHK( hipMemcpy( sc->d_prog, img.data(), size_t( sc->prog_bytes ), hipMemcpyHostToDevice ) );
+	}
 	HIPCHK( hipMalloc( &sc->d_counters, 4 * sizeof( unsigned long long ) ) );
 	if( efn != nullptr ){
 		std::vector<int16_t>	t16;
@@ -642,6 +660,18 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	hipDeviceProp_t	prop;
 	HIPCHK( hipGetDeviceProperties( &prop, device ) );
 	sc->grid_blocks = prop.multiProcessorCount * 8;
+	if( sc->dprog.lean_ok ){
+		// The search of a tile ends with a few long-running items on a few lanes, so fewer,
+		// larger tiles are better as long as four workgroups still share a CU's 160 KB of
+		// LDS (measured on trna.descr, ms per 100 Mbase: T = 2048 6.97, 4096 5.87, 6144 5.40,
+		// and 6.9 again at 8192 where only three fit).
+		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 256;
+		for( int t = 8192; t >= 2048; t -= 512 )
+			if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true ) <= budget ){
+				sc->tile_t = t;
+				break;
+			}
+	}
 	const char	*tt = getenv( "RNAMOTIF_TILE" );
 	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 16384 )
 		sc->tile_t = atoi( tt );
@@ -819,13 +849,10 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		return 0;
 	DbView	v = view_of( sc, db );
 	const rmd_program_t	&dp = sc->dprog;
-	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
-	size_t	lds = PROG_LDS_BYTES + QCAP * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
 	const int	dbg = getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0;
 	const bool	lean = dp.lean_ok && !( dbg & 16 );
-	if( lean )
-		lds += size_t( dp.n_searches ) * BLOCK * sizeof( rmd_lrec_t );
+	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
+	size_t	lds = search_lds_bytes( sc->prog_bytes, dp, sc->tile_t, lean );
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;
@@ -841,10 +868,10 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		if( lean )
 			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, v, hb, tile_bytes, dbg );
+				sc->d_prog, sc->prog_bytes, v, hb, tile_bytes, dbg );
 		else
 			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, false> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, v, hb, tile_bytes, dbg );
+				sc->d_prog, sc->prog_bytes, v, hb, tile_bytes, dbg );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );

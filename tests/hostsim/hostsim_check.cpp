@@ -71,7 +71,7 @@ static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int sl
 	for( int szero = 0; szero <= slen - dp->dminlen; szero++ ){
 		if( dp->lit_re >= 0 && !getenv( "HOSTSIM_NOQUICK" ) ){
 			// best-literal filter, as in the kernel
-			const rmd_regex_t	&lre = dp->regexes[ dp->lit_re ];
+			const rmd_regex_t	&lre = rmd_regexes( dp )[ dp->lit_re ];
 			int	n = lre.n_states, hi = std::min( dp->lit_hi, dp->w_winsize - n );
 			bool	found = false;
 			for( int q = szero + dp->lit_lo; q <= szero + hi && !found; q++ ){
