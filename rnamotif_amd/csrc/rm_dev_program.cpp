@@ -354,6 +354,39 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 						out->lit_re = e.re;
 						out->lit_lo = lo;
 						out->lit_hi = hi;
+						// the same literal seen from the end of the first search element's group
+						// (its end position is what a rank of the first level fixes): distance
+						// from the literal's first base to that end
+						out->lit_elo = 0;
+						out->lit_ehi = -1;
+						const rma_elem_t	&g0 = p->elems[ p->searches[ 0 ] ];
+						const int	g_last = g0.n_scopes > 0 ? g0.scopes[ g0.n_scopes - 1 ] : g0.index;
+						if( i >= g0.index && i <= g_last ){
+							long	smin = 0, smax = 0;
+							bool	unb = false;
+							for( int j = i + 1; j <= g_last; j++ ){
+								smin += p->elems[ j ].minlen;
+								if( p->elems[ j ].maxlen == RMA_UNBOUNDED )
+									unb = true;
+								else
+									smax += p->elems[ j ].maxlen;
+							}
+							long	dlo, dhi;
+							if( re.anchored && !re.dollar ){
+								dlo = e.minlen - 1 + smin;
+								dhi = e.maxlen - 1 + smax;
+							}else if( re.dollar ){
+								dlo = n - 1 + smin;
+								dhi = n - 1 + smax;
+							}else{
+								dlo = n - 1 + smin;
+								dhi = e.maxlen - 1 + smax;
+							}
+							if( !unb && dhi >= dlo && dhi < 30000 ){
+								out->lit_elo = int32_t( dlo );
+								out->lit_ehi = int32_t( dhi );
+							}
+						}
 					}
 				}
 			}

@@ -95,6 +95,8 @@ struct rmd_program_t {
 	// best-literal pre-filter (the role of the reference's -O, compile.c:3315): regex lit_re
 	// must occur with its first base at an offset in [lit_lo, lit_hi] from the start position
 	int32_t	lit_re, lit_lo, lit_hi;
+	int32_t	lit_elo, lit_ehi;	// ... and at a distance in [lit_elo, lit_ehi] before the end of the first
+					// search element's group (lit_ehi < 0: not known)
 	// The three pools at the end are reached through byte offsets from the start of the
 	// program (rmd_pairsets() ...), so that the image a workgroup copies into LDS holds only
 	// what the descriptor uses: the members up to elems[ n_elems ], then the used regexes,

@@ -583,6 +583,7 @@ RMD_FN int rmd_find_maxlen( const rmd_program_t *P, const rmd_lane_t *L, int fd,
 RMD_FN void rmd_unmark( rmd_lane_t *L, int d ) { L->moff[ d ] = L->mlen[ d ] = RMD_UNDEF; }
 RMD_FN void rmd_mark( rmd_lane_t *L, int d, int off, int len ) { L->moff[ d ] = off; L->mlen[ d ] = len; }
 RMD_FN int rmd_imin( int a, int b ) { return a < b ? a : b; }
+RMD_FN int rmd_imax( int a, int b ) { return a > b ? a : b; }
 
 RMD_FN int rmd_s3lim( int szero, int sdollar, int i_minl, int h_maxl )	// find_motif.c:426-429
 {

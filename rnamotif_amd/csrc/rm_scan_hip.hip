@@ -221,12 +221,13 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 			}
 			__syncthreads();
 		}
-#define LIT_OK( szero_, res_ )	do{ \
+		// does the literal start anywhere in [a_, b_] (absolute positions)?
+#define LIT_IN( a_, b_, res_ )	do{ \
 		res_ = true; \
 		if( lit ){ \
 			res_ = false; \
-			const int	b1_ = ( szero_ ) + lit_hi - p_lo + 64; \
-			for( int b0_ = ( szero_ ) + P->lit_lo - p_lo + 64; b0_ <= b1_ && !res_; b0_ += 64 ){ \
+			const int	b1_ = ( b_ ) - p_lo + 64; \
+			for( int b0_ = ( a_ ) - p_lo + 64; b0_ <= b1_ && !res_; b0_ += 64 ){ \
 				const int	wi_ = b0_ >> 6, sh_ = b0_ & 63; \
 				unsigned long long	x_ = sh_ ? ( occ[ wi_ ] >> sh_ ) | ( occ[ wi_ + 1 ] << ( 64 - sh_ ) ) : occ[ wi_ ]; \
 				const int	nb_ = b1_ - b0_ + 1; \
@@ -235,6 +236,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 				res_ = x_ != 0; \
 			} \
 		} }while( 0 )
+#define LIT_OK( szero_, res_ )	LIT_IN( ( szero_ ) + P->lit_lo, ( szero_ ) + lit_hi, res_ )
 
 		// push( pred, item ): one ballot + prefix count per call; overflow is searched in place
 #define QPUSH( pred, item, szero_, r0_, cnt_ )	do{ \
@@ -350,8 +352,21 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 						any = any && rmd_prefix_ok( P, e0, sq, szero );
 					}
 					if( split_ranks ){
-						for( int r = 0; r < n_rank; r++ )
-							QPUSH( any && r <= hi - lo, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+						for( int r = 0; r < n_rank; r++ ){
+							bool	pred = any && r <= hi - lo;
+							if( pred && P->lit_ehi >= 0 ){
+								// the rank fixes the end of the knot: the literal must also sit at
+								// an admissible distance from that end
+								const int	e_ = hi - r;
+								const int	a_ = rmd_imax( szero + P->lit_lo, e_ - P->lit_ehi );
+								const int	b_ = rmd_imin( szero + lit_hi, e_ - P->lit_elo );
+								if( a_ > b_ )
+									pred = false;
+								else
+									LIT_IN( a_, b_, pred );
+							}
+							QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+						}
 					}else
 						QPUSH( any, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
 					continue;
@@ -388,9 +403,20 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 				if( split_ranks ){
 					// few start positions survive the filters: hand their end positions
 					// out one by one so that the lanes of pass B all get work
-					const bool	pred = valid && r <= hi - lo && ( r > 0 || !e0_at_szero || rmd_prefix_ok( P, e0, sq, szero ) );
+					bool	pred = valid && r <= hi - lo && ( r > 0 || !e0_at_szero || rmd_prefix_ok( P, e0, sq, szero ) );
 					if( r == 0 && valid && !pred )
 						valid = false;
+					if( pred && P->lit_ehi >= 0 ){
+						// this rank fixes the end of the first element's group: the literal must
+						// also sit at an admissible distance from that end
+						const int	e_ = hi - r;
+						const int	a_ = rmd_imax( szero + P->lit_lo, e_ - P->lit_ehi );
+						const int	b_ = rmd_imin( szero + lit_hi, e_ - P->lit_elo );
+						if( a_ > b_ )
+							pred = false;
+						else
+							LIT_IN( a_, b_, pred );
+					}
 					QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
 				}else if( quick ){
 					const int	sd = hi - r;
@@ -407,6 +433,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 		}
 #undef QPUSH
 #undef LIT_OK
+#undef LIT_IN
 		__syncthreads();
 
 		// ---- pass B: the full search.  Lanes are persistent within the tile: a lane
