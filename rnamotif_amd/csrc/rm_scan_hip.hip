@@ -563,7 +563,9 @@ struct rma_scanner {
 	int32_t	*d_hits = nullptr;
 	int64_t	hit_cap = 0;
 	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
-	std::vector<int32_t>	h_raw, h_sorted;
+	int32_t	*h_raw = nullptr;		// pinned
+	size_t	h_raw_cap = 0;
+	std::vector<int32_t>	h_sorted;
 	int	tile_t = 2048;
 	int	grid_blocks = 0;
 };
@@ -714,6 +716,8 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 		return;
 	( void )hipSetDevice( sc->device );
 	( void )hipFree( sc->d_prog );
+	if( sc->h_raw != nullptr )
+		( void )hipHostFree( sc->h_raw );
 	( void )hipFree( sc->d_t16 );
 	( void )hipFree( sc->d_tlkey );
 	( void )hipFree( sc->d_loginc );
@@ -949,12 +953,22 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 	if( n == 0 )
 		return 0;
 	const int	stride = sc->dprog.hit_stride;
-	sc->h_raw.resize( size_t( n ) * stride );
-	HIPCHK( hipMemcpy( sc->h_raw.data(), sc->d_hits, sc->h_raw.size() * sizeof( int32_t ), hipMemcpyDeviceToHost ) );
+	// pinned staging buffer: the copy back is a single DMA
+	const size_t	words = size_t( n ) * stride;
+	if( words > sc->h_raw_cap ){
+		if( sc->h_raw != nullptr )
+			( void )hipHostFree( sc->h_raw );
+		sc->h_raw = nullptr;
+		sc->h_raw_cap = 0;
+		HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_raw ), words * 2 * sizeof( int32_t ), hipHostMallocDefault ) );
+		sc->h_raw_cap = words * 2;
+	}
+	HIPCHK( hipMemcpyAsync( sc->h_raw, sc->d_hits, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
+	HIPCHK( hipStreamSynchronize( sc->stream ) );
 	// reference order: (seq, comp, szero, rank, order)
 	std::vector<int64_t>	idx( n );
 	std::iota( idx.begin(), idx.end(), 0 );
-	const int32_t	*d = sc->h_raw.data();
+	const int32_t	*d = sc->h_raw;
 	std::sort( idx.begin(), idx.end(), [ & ]( int64_t a, int64_t b ){
 		const int32_t	*x = d + a * stride, *y = d + b * stride;
 		for( int k = 0; k < RMA_HIT_HDR; k++ )
@@ -962,7 +976,7 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 				return x[ k ] < y[ k ];
 		return false;
 	} );
-	sc->h_sorted.resize( sc->h_raw.size() );
+	sc->h_sorted.resize( words );
 	for( int64_t i = 0; i < n; i++ )
 		memcpy( &sc->h_sorted[ size_t( i ) * stride ], d + idx[ i ] * stride, stride * sizeof( int32_t ) );
 	*hits = sc->h_sorted.data();
