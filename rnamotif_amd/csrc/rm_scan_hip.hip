@@ -102,8 +102,13 @@ struct LdsRecs {
 // LEAN: the descriptor has only ss and proper helices (rmd_program_t::lean_ok) -- pass B keeps
 // 8 bytes of state per level in LDS; the general state machine is not compiled into that
 // instance at all (no scratch frames, fewer registers).
+// (the general instance keeps its frames in scratch and is latency bound on them: six
+// waves per SIMD at 80 VGPRs beat four at 128 -- pk1 48.5 -> 41.9 ms, qu+tr 124 -> 94 ms)
+#ifndef GENERAL_WAVES_PER_SIMD
+#define GENERAL_WAVES_PER_SIMD	6
+#endif
 template< int BLOCK, bool LEAN >
-__global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
+__global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES_PER_SIMD )
 rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
