@@ -43,15 +43,23 @@ int	rma_descr_compile( int argc, const char *const *argv, rma_descr_t **out, cha
 void	rma_descr_free( rma_descr_t *d );
 const rma_program_t	*rma_descr_program( const rma_descr_t *d );
 const rma_efndata_t	*rma_descr_efndata( const rma_descr_t *d );	/* NULL: no efn() in the score section */
+const rma_efn2data_t	*rma_descr_efn2data( const rma_descr_t *d );	/* NULL: no efn2() in the score section */
 int	rma_descr_minlen( const rma_descr_t *d );			/* rm_dminlen */
 int	rma_descr_maxlen( const rma_descr_t *d );			/* rm_dmaxlen, RMA_UNBOUNDED if open */
 /* for bindings that do not want to mirror the struct: n_elems, n_searches, hit stride,
  * ctx offset, efn offset, n_efn_sites, chk_both_strs, windowsize */
 void	rma_program_info( const rma_program_t *prog, int32_t info[ 8 ] );
 
+/* ---- energy tables on their own: RM_getefndata() efn.c:157 / RM_getefn2data() efn2.c:130
+ * from the directory dir (the reference's efn_datadir / $EFNDATA). */
+int	rma_efndata_load( const char *dir, rma_efndata_t *out, char *err, size_t errlen );
+int	rma_efn2data_load( const char *dir, rma_efn2data_t *out, char *err, size_t errlen );
+
 /* ---- scanner.  prog (and efn, may be NULL) are copied. */
 int	rma_scanner_create( const rma_program_t *prog, const rma_efndata_t *efn, int device,
 		rma_scanner_t **out, char *err, size_t errlen );
+/* tables for the program's efn2() sites (RM_getefn2data, efn2.c:130); copied to the device */
+int	rma_scanner_set_efn2data( rma_scanner_t *sc, const rma_efn2data_t *efn2, char *err, size_t errlen );
 void	rma_scanner_destroy( rma_scanner_t *sc );
 
 /* ---- database: n sequences of lower case letters as the reference's readers

@@ -126,7 +126,10 @@ typedef struct rma_site {
  * the way do_sc_efnx does (pos 0-based; pos2 < 0 means "last base of idx2"). */
 typedef struct rma_efn_site {
 	int32_t	idx, pos, idx2, pos2;
+	int32_t	kind;			/* 0: efn() (efn.c:1162), 1: efn2() (efn2.c:1103) */
 } rma_efn_site_t;
+#define RMA_EFN_KIND_EFN	0
+#define RMA_EFN_KIND_EFN2	1
 
 typedef struct rma_program {
 	uint32_t	magic;
@@ -180,6 +183,39 @@ typedef struct rma_efndata {
 	int32_t	loginc[ RMA_EFN_LOGINC ];
 	float	prelog;
 } rma_efndata_t;
+
+/* Tables of efn2(), the in-memory form of EFN2DATA_T (efn2.c:22-66), integer 1/100
+ * kcal/mol with EFN2_INFINITY = 9999999.  loginc[n] = (int)( prelog*log( n/30. ) )
+ * (truncated, efn2.c:1570,1583,1650) and mbl_log[n] = (int)( 11.*log( n/6. ) + 0.5 )
+ * (efn2.c:1209) are computed on the host in the reference's arithmetic. */
+#define RMA_EFN2_INFINITY	9999999
+#define RMA_EFN2_MAXTLOOP	100
+typedef struct rma_efn2data {
+	int32_t	inter[ 31 ], bulge[ 31 ], hairpin[ 31 ];
+	int32_t	dangle[ 5 ][ 5 ][ 5 ][ 2 ];
+	int32_t	maxpen;
+	int32_t	poppen[ 5 ];
+	int32_t	eparam[ 11 ];
+	int32_t	efn2a, efn2b, efn2c, auend, gubonus, cslope, cint, c3, init, gail;
+	int32_t	tloop[ RMA_EFN2_MAXTLOOP + 1 ][ 2 ];	/* 1-based, base-5 keys (efn2.c:1050) */
+	int32_t	ntloops;
+	int32_t	triloop[ RMA_EFN2_MAXTLOOP + 1 ][ 2 ];
+	int32_t	ntriloops;
+	int32_t	stack[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	tstkh[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	tstki[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	coax[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	tstackcoax[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	coaxstack[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	tstack[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	tstkm[ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	iloop11[ 5 ][ 5 ][ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	iloop21[ 5 ][ 5 ][ 5 ][ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	iloop22[ 5 ][ 5 ][ 5 ][ 5 ][ 5 ][ 5 ][ 5 ][ 5 ];
+	int32_t	loginc[ RMA_EFN_LOGINC ];
+	int32_t	mbl_log[ RMA_EFN_LOGINC ];
+	float	prelog;
+} rma_efn2data_t;
 
 /* Hit record: int32 words, stride = rma_hit_stride( prog ).
  *   [0] seq     index of the sequence in the batch

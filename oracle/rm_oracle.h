@@ -49,6 +49,12 @@ int	rmo_load_efndata( const char *dir, rma_efndata_t *ed );
 /* RM_efn( 0, l_base, 1 ) on bcseq/basepr[0..l_base], efn.c:1162 */
 int	rmo_efn( const rma_efndata_t *ed, const int *bcseq, const int *basepr, int l_base );
 
+/* RM_efn2() on bcseq/basepr[0..l_base] (basepr -1 = unpaired), efn2.c:1103; tables as
+ * the product's loader fills them (rma_efn2data_load).  *undefined is set, and
+ * RMA_EFN2_INFINITY returned, where the reference would index outside its arrays. */
+void	rmo_set_efn2data( const rma_efn2data_t *ed );	/* used by rmo_scan for efn2() sites */
+int	rmo_efn2( const rma_efn2data_t *ed, const int *bcseq, const int *basepr, int l_base, int *undefined );
+
 #ifdef __cplusplus
 }
 #endif

@@ -657,6 +657,9 @@ static	int	chk_sites( ctx_t *c )	/* :1758, chk_1_site :1769 */
 }
 
 /* ------------------------------------------------------------------ efn at the candidate */
+static	const rma_efn2data_t	*rmo_efn2data = NULL;	/* tables for efn2() sites, set by the tests */
+void	rmo_set_efn2data( const rma_efn2data_t *ed ) { rmo_efn2data = ed; }
+
 static	int	efn_site( ctx_t *c, const rma_efn_site_t *es )	/* setupefn/setbp, score.c:3128-3250 */
 {
 	const rma_program_t	*p = c->p;
@@ -713,6 +716,10 @@ static	int	efn_site( ctx_t *c, const rma_efn_site_t *es )	/* setupefn/setbp, sco
 			}
 		}
 	}
+	if( es->kind == RMA_EFN_KIND_EFN2 ){
+		int	undefined;
+		return( rmo_efn2data ? rmo_efn2( rmo_efn2data, bcseq, basepr, len - 1, &undefined ) : RMA_EFN2_INFINITY );
+	}
 	return( rmo_efn( c->ed, bcseq, basepr, len - 1 ) );
 }
 
@@ -747,7 +754,7 @@ static	void	emit_hit( ctx_t *c )	/* find_ss :373-392 up to RM_score() */
 	w[ k + 3 ] = p->has_rctx ? c->r_len : 0;
 	k = rma_hit_efn_off( p );
 	for( d = 0; d < p->n_efn_sites; d++ )
-		w[ k + d ] = c->ed ? efn_site( c, &p->efn_sites[ d ] ) : RMA_EFN_INFINITY;
+		w[ k + d ] = ( c->ed || p->efn_sites[ d ].kind == RMA_EFN_KIND_EFN2 ) ? efn_site( c, &p->efn_sites[ d ] ) : RMA_EFN_INFINITY;
 	h->n++;
 }
 

@@ -68,8 +68,9 @@ int oracle_scan( void *self, const char *const *seqs, const int32_t *slens, int 
 	return 0;
 }
 
-rma::ScanBackend make_oracle( const rma_program_t *prog, const rma_efndata_t *efn )
+rma::ScanBackend make_oracle( const rma_program_t *prog, const rma_efndata_t *efn, const rma_efn2data_t *efn2 )
 {
+	rmo_set_efn2data( efn2 );	// tables for efn2() sites: the product's loader (checked against efn2_drv)
 	OracleBackend	*ob = new OracleBackend;
 	ob->prog = prog;
 	ob->efn = efn;

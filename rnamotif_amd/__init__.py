@@ -55,6 +55,9 @@ def lib() -> C.CDLL:
     L.rma_descr_program.argtypes = [vp]
     L.rma_descr_program.restype = vp
     L.rma_descr_efndata.argtypes = [vp]
+    L.rma_descr_efn2data.argtypes = [vp]
+    L.rma_descr_efn2data.restype = vp
+    L.rma_scanner_set_efn2data.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     L.rma_descr_efndata.restype = vp
     L.rma_descr_minlen.argtypes = [vp]
     L.rma_descr_maxlen.argtypes = [vp]
@@ -125,6 +128,7 @@ class Descriptor:
         self._h = h
         self.program = L.rma_descr_program(h)
         self.efndata = L.rma_descr_efndata(h)
+        self.efn2data = L.rma_descr_efn2data(h)
         info = (C.c_int32 * 8)()
         L.rma_program_info(self.program, info)
         (self.n_elems, self.n_searches, self.hit_stride, self.ctx_off, self.efn_off,
@@ -199,6 +203,8 @@ class Scanner:
         err = C.create_string_buffer(_ERRLEN)
         _check(L.rma_scanner_create(descr.program, descr.efndata, device, C.byref(h), err, _ERRLEN), err)
         self._h = h
+        if descr.efn2data:
+            _check(L.rma_scanner_set_efn2data(h, descr.efn2data, err, _ERRLEN), err)
 
     def database(self, seqs: Sequence[bytes], ranges: Optional[Sequence[Tuple[int, int]]] = None) -> Database:
         return Database(self, seqs, ranges=ranges)

@@ -3,6 +3,7 @@
 // rm_scan_hip.hip.
 #include "rnamotif_amd.h"
 #include "rm_cli.h"
+#include "rm_efndata.h"
 #include <cstring>
 
 struct rma_descr {
@@ -52,6 +53,7 @@ extern "C" int rma_descr_compile( int argc, const char *const *argv, rma_descr_t
 }
 
 extern "C" void rma_descr_free( rma_descr_t *d ) { delete d; }
+extern "C" const rma_efn2data_t *rma_descr_efn2data( const rma_descr_t *d ) { return d->pr.efn2.get(); }
 extern "C" const rma_program_t *rma_descr_program( const rma_descr_t *d ) { return d->pr.prog.get(); }
 extern "C" const rma_efndata_t *rma_descr_efndata( const rma_descr_t *d ) { return d->pr.efn.get(); }
 extern "C" int rma_descr_minlen( const rma_descr_t *d ) { return d->pr.descr->dminlen; }
@@ -205,4 +207,25 @@ const rma_pack_t *rma_pack_wrap( const rma::PackFile *pf )
 {
 	static_assert( offsetof( rma_pack, pf ) == 0, "rma_pack wraps exactly one PackFile" );
 	return reinterpret_cast<const rma_pack_t *>( pf );
+}
+
+// ---------------------------------------------------------------- energy tables
+extern "C" int rma_efndata_load( const char *dir, rma_efndata_t *out, char *err, size_t errlen )
+{
+	std::string	e;
+	if( !rma::load_efndata( dir ? dir : "", out, e ) )
+		return set_err( err, errlen, e.c_str() );
+	return 0;
+}
+
+extern "C" int rma_efn2data_load( const char *dir, rma_efn2data_t *out, char *err, size_t errlen )
+{
+	std::string	e;
+	try{
+		if( !rma::load_efn2data( dir ? dir : "", out, e ) )
+			return set_err( err, errlen, e.c_str() );
+	}catch( rma::Error &x ){
+		return set_err( err, errlen, x.what() );
+	}
+	return 0;
 }

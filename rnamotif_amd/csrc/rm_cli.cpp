@@ -21,7 +21,10 @@ Prepared prepare( const Args &args )
 	pr.prog->n_efn_sites = int( ec.size() );
 	for( size_t k = 0; k < ec.size(); k++ )
 		pr.prog->efn_sites[ k ] = ec[ k ].site;
-	if( !ec.empty() && !args.copt ){
+	bool	any_efn = false, any_efn2 = false;
+	for( const EfnCall &c : ec )
+		( c.site.kind == RMA_EFN_KIND_EFN2 ? any_efn2 : any_efn ) = true;
+	if( any_efn && !args.copt ){
 		pr.efn.reset( new rma_efndata_t );
 		std::string	err, dir = find_efndata_dir( d );
 		if( !load_efndata( dir, pr.efn.get(), err ) ){
@@ -29,6 +32,12 @@ Prepared prepare( const Args &args )
 			// scores with whatever was read.  Report and continue likewise.
 			fputs( err.c_str(), stderr );
 		}
+	}
+	if( any_efn2 && !args.copt ){
+		pr.efn2.reset( new rma_efn2data_t );
+		std::string	err, dir = find_efndata_dir( d );
+		if( !load_efn2data( dir, pr.efn2.get(), err ) )	// score.c:1611, likewise not fatal there
+			fputs( err.c_str(), stderr );
 	}
 	return pr;
 }
@@ -68,7 +77,7 @@ int cli_main( int argc, char **argv, BackendFactory make_backend )
 			d.score->dump( stderr );
 		if( args.copt )
 			return 0;
-		ScanBackend	be = make_backend( pr.prog.get(), pr.efn.get() );
+		ScanBackend	be = make_backend( pr.prog.get(), pr.efn.get(), pr.efn2.get() );
 		const char	*bb = getenv( "RNAMOTIF_BATCH_BASES" );
 		int64_t	batch_bases = bb ? atoll( bb ) : ( int64_t( 1 ) << 28 );
 		run_search( d, *pr.prog, be, stdout, batch_bases, nullptr );

@@ -8,13 +8,14 @@ namespace rma {
 
 // Build the scanner for a compiled program; efn is null when the score
 // program has no efn() call.  Throws Error on failure.
-typedef ScanBackend ( *BackendFactory )( const rma_program_t *prog, const rma_efndata_t *efn );
+typedef ScanBackend ( *BackendFactory )( const rma_program_t *prog, const rma_efndata_t *efn, const rma_efn2data_t *efn2 );
 
 // Prepared search: compiled descriptor + flattened program (+ energy tables).
 struct Prepared {
 	std::unique_ptr<Descriptor>	descr;
 	std::unique_ptr<rma_program_t>	prog;
 	std::unique_ptr<rma_efndata_t>	efn;	// null if unused
+	std::unique_ptr<rma_efn2data_t>	efn2;	// null unless the score section calls efn2()
 };
 
 // RM_init .. RM_linkscore, rnamot.c:49-98, plus flattening.

@@ -43,12 +43,14 @@ int hip_scan_packed( void *self, const rma::PackFile *pk, int first, int count,
 	return rma_scan( hb->sc, hb->db, hits, n_hits, err, errlen );
 }
 
-rma::ScanBackend make_hip( const rma_program_t *prog, const rma_efndata_t *efn )
+rma::ScanBackend make_hip( const rma_program_t *prog, const rma_efndata_t *efn, const rma_efn2data_t *efn2 )
 {
 	HipBackend	*hb = new HipBackend;
 	char	err[ 1024 ] = "";
 	const char	*dv = getenv( "RNAMOTIF_DEVICE" );
 	if( rma_scanner_create( prog, efn, dv ? atoi( dv ) : 0, &hb->sc, err, sizeof( err ) ) )
+		rma::fail( "%s", err );
+	if( efn2 != nullptr && rma_scanner_set_efn2data( hb->sc, efn2, err, sizeof( err ) ) )
 		rma::fail( "%s", err );
 	return rma::ScanBackend{ hb, hip_scan, hip_scan_packed };
 }

@@ -29,6 +29,7 @@
 #define RMD_FN_MEMBER	__device__ inline
 #include "rm_scan_core.h"
 #include "rm_efn_core.h"
+#include "rm_efn2_core.h"
 #include "rm_fasta.h"
 #include "rm_pack.h"
 #include "rnamotif_amd.h"
@@ -533,11 +534,12 @@ struct DevSeq {
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK )
 rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
-	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc )
+	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc, const rma_efn2data_t *e2 )
 {
 	__shared__ int16_t	t16[ RME_N16 ];
-	for( int i = threadIdx.x; i < RME_N16; i += BLOCK )
-		t16[ i ] = g16[ i ];
+	if( g16 != nullptr )
+		for( int i = threadIdx.x; i < RME_N16; i += BLOCK )
+			t16[ i ] = g16[ i ];
 	__syncthreads();
 	long long	h = ( long long )blockIdx.x * BLOCK + threadIdx.x;
 	if( h >= n_hits )
@@ -546,8 +548,12 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 	int32_t	*w = hits + h * gP->hit_stride;
 	DevSeq	sq{ db, db.base_off[ w[ 0 ] ], db.slen[ w[ 0 ] ], w[ 1 ] };
 	const int	efn_off = RMA_HIT_HDR + 4 * gP->n_elems + 4;
-	for( int k = 0; k < gP->n_efn; k++ )
-		w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k );
+	for( int k = 0; k < gP->n_efn; k++ ){
+		if( gP->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
+			w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy( gP, e2, &sq, w, k ) : RME2_INF;
+		else if( g16 != nullptr )
+			w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k );
+	}
 }
 
 // ---------------------------------------------------------------- host side
@@ -560,6 +566,8 @@ struct rma_scanner {
 	int	device = 0;
 	hipStream_t	stream = nullptr;
 	hipEvent_t	ev[ 4 ] = { nullptr, nullptr, nullptr, nullptr };
+	rma_efn2data_t	*d_efn2 = nullptr;	// efn2() tables, global memory
+	bool	need_efn2 = false;
 	rmd_program_t	*d_prog = nullptr;	// compact image, prog_bytes long
 	int	prog_bytes = 0;
 	int16_t	*d_t16 = nullptr;
@@ -661,10 +669,14 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		delete sc;
 		return 1;
 	}
-	if( prog->n_efn_sites > 0 && efn == nullptr ){
-		snprintf( err, errlen, "the program has efn() call sites but no energy tables were given" );
-		delete sc;
-		return 1;
+	for( int k = 0; k < prog->n_efn_sites; k++ ){
+		if( prog->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
+			sc->need_efn2 = true;	// tables come with rma_scanner_set_efn2data(), checked at the first scan
+		else if( efn == nullptr ){
+			snprintf( err, errlen, "the program has efn() call sites but no energy tables were given" );
+			delete sc;
+			return 1;
+		}
 	}
 	sc->device = device;
 	HIPCHK( hipSetDevice( device ) );
@@ -715,12 +727,22 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	return 0;
 }
 
+extern "C" int rma_scanner_set_efn2data( rma_scanner_t *sc, const rma_efn2data_t *efn2, char *err, size_t errlen )
+{
+	HIPCHK( hipSetDevice( sc->device ) );
+	if( sc->d_efn2 == nullptr )
+		HIPCHK( hipMalloc( &sc->d_efn2, sizeof( rma_efn2data_t ) ) );
+	HIPCHK( hipMemcpy( sc->d_efn2, efn2, sizeof( rma_efn2data_t ), hipMemcpyHostToDevice ) );
+	return 0;
+}
+
 extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 {
 	if( sc == nullptr )
 		return;
 	( void )hipSetDevice( sc->device );
 	( void )hipFree( sc->d_prog );
+	( void )hipFree( sc->d_efn2 );
 	if( sc->h_raw != nullptr )
 		( void )hipHostFree( sc->h_raw );
 	( void )hipFree( sc->d_t16 );
@@ -881,6 +903,10 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	*n_hits = 0;
 	if( search_ms ) *search_ms = 0;
 	if( efn_ms ) *efn_ms = 0;
+	if( sc->need_efn2 && sc->d_efn2 == nullptr ){
+		snprintf( err, errlen, "the program has efn2() call sites but rma_scanner_set_efn2data() was not called" );
+		return 1;
+	}
 	if( db->n_tiles == 0 )
 		return 0;
 	DbView	v = view_of( sc, db );
@@ -932,12 +958,13 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	if( search_ms )
 		HIPCHK( hipEventElapsedTime( search_ms, sc->ev[ 0 ], sc->ev[ 1 ] ) );
 	*n_hits = int64_t( count );
-	if( sc->have_efn && dp.n_efn > 0 && count > 0 ){
+	if( ( sc->have_efn || sc->d_efn2 != nullptr ) && dp.n_efn > 0 && count > 0 ){
 		constexpr int	EB = 64;
 		int64_t	blocks = ( int64_t( count ) + EB - 1 ) / EB;
 		HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
 		hipLaunchKernelGGL( rma_efn_kernel<EB>, dim3( unsigned( blocks ) ), dim3( EB ), 0, sc->stream,
-			sc->d_prog, v, sc->d_hits, ( long long )count, sc->d_t16, sc->d_tlkey, sc->d_loginc );
+			sc->d_prog, v, sc->d_hits, ( long long )count, sc->have_efn ? sc->d_t16 : nullptr, sc->d_tlkey, sc->d_loginc,
+			sc->d_efn2 );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 3 ], sc->stream ) );
 		HIPCHK( hipStreamSynchronize( sc->stream ) );

@@ -372,8 +372,8 @@ void ScoreVM::fix_call( Node *np )	// :1000
 			fail( "%s:%d function '%s' takes only strel arguments.", a1->filename, a1->lineno, scnames[ sc ] );
 		if( !is_stref( a2 ) )
 			fail( "%s:%d function '%s' takes only strel arguments.", a2->filename, a2->lineno, scnames[ sc ] );
-		if( sc == SC_EFN )
-			note_efn_call( np, a1, a2 );
+		if( sc == SC_EFN || sc == SC_EFN2 )
+			note_efn_call( np, a1, a2, sc == SC_EFN2 );
 		Node	*l1 = a1->right, *tail = l1;
 		while( tail->right )
 			tail = tail->right;
@@ -423,11 +423,12 @@ void ScoreVM::fix_call( Node *np )	// :1000
 
 // The scanner evaluates efn() on the device, so the elements and positions an
 // efn() call refers to must be known when the descriptor is compiled.
-void ScoreVM::note_efn_call( Node *call, Node *a1, Node *a2 )
+void ScoreVM::note_efn_call( Node *call, Node *a1, Node *a2, bool efn2 )
 {
 	EfnCall	ec;
 	ec.call = call;
 	memset( &ec.site, 0, sizeof( ec.site ) );
+	ec.site.kind = efn2 ? RMA_EFN_KIND_EFN2 : RMA_EFN_KIND_EFN;
 	// a?->right is LIST( STRID-call, LIST( pos, LIST( len ) ) ) after fix_*_stref
 	auto konst = [&]( Node *n, bool allow_str ) -> bool {
 		if( n->sym == SYM_INT )
@@ -1218,8 +1219,7 @@ float ScoreVM::do_bits( const Inst &ip )	// do_sc_bits :1502, RM_bits :3084
 float ScoreVM::do_efn( const Inst &ip )	// do_sc_efnx :1567
 {
 	int	sc = ip.val.ival;
-	if( sc == SC_EFN2 )
-		fail( "%s:%d efn2() is not available in this build.", ip.filename, ip.lineno );
+	const int	kind = sc == SC_EFN2 ? RMA_EFN_KIND_EFN2 : RMA_EFN_KIND_EFN;
 	int	idx = mem_[ sp_ - 5 ].ival;
 	Strel	*stp = xd( ip, idx, "efn" );
 	int	pos = mem_[ sp_ - 4 ].ival;
@@ -1252,10 +1252,10 @@ float ScoreVM::do_efn( const Inst &ip )	// do_sc_efnx :1567
 	for( size_t k = 0; k < efn_calls_.size(); k++ ){
 		const rma_efn_site_t	&s = efn_calls_[ k ].site;
 		int	want2 = s.pos2 < 0 ? stp2->matchlen - 1 : s.pos2;
-		if( s.idx + x_off == idx && s.idx2 + x_off == idx2 && s.pos == pos && want2 == pos2 ){
+		if( s.kind == kind && s.idx + x_off == idx && s.idx2 + x_off == idx2 && s.pos == pos && want2 == pos2 ){
 			if( efn_vals_ == nullptr )
 				fail( "%s:%d efn(): no device energies for this candidate.", ip.filename, ip.lineno );
-			float	rval = 0.01 * efn_vals_[ k ];	// score.c:1675: float rval = 0.01 * RM_efn()
+			float	rval = 0.01 * efn_vals_[ k ];	// score.c:1675-1677: float rval = 0.01 * RM_efn() / RM_efn2()
 			return rval;
 		}
 	}

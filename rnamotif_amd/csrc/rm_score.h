@@ -104,7 +104,7 @@ private:
 	void	fix_ix_stref( Node *np );
 	void	fix_stref_common( Node *np, int sel, Node *n_id, Node *n_pos, Node *n_len );
 	void	fix_call( Node *np );
-	void	note_efn_call( Node *call, Node *a1, Node *a2 );
+	void	note_efn_call( Node *call, Node *a1, Node *a2, bool efn2 );
 
 	void	do_scl( const Inst &ip );
 	int	strid( int stype, Value *v_id );

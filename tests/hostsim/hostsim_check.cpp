@@ -14,7 +14,24 @@
 #include "rm_cli.h"
 #include "rm_oracle.h"
 #define RMD_FN static inline
+#define RMD_FN_MEMBER inline
 #include "rm_scan_core.h"
+#include "rm_efn2_core.h"
+
+// strand view for the energy cores: code( p ) of the strand the hit lies on
+struct HostSeq {
+	const char	*sbuf;
+	int	code( int p ) const
+	{
+		switch( sbuf[ p ] ){
+		case 'a' : return 0;
+		case 'c' : return 1;
+		case 'g' : return 2;
+		case 't' : case 'u' : return 3;
+		default : return 4;
+		}
+	}
+};
 
 struct VecSink {
 	std::vector<int32_t>	*out;
@@ -117,7 +134,7 @@ int main( int argc, char **argv )
 			return 2;
 		}
 		int	stride = dp.hit_stride, n_cmp = rma_hit_efn_off( pr.prog.get() );
-		int64_t	total = 0, bad = 0;
+		int64_t	total = 0, bad = 0, n_efn2 = 0;
 		int	seq = 0;
 		for( const std::string &fn : args.dbfnames ){
 			FILE	*fp = fopen( fn.c_str(), "r" );
@@ -133,6 +150,7 @@ int main( int argc, char **argv )
 						rmo_revcomp( buf.data(), slen );
 					rmo_hits_t	oh;
 					rmo_hits_init( &oh, pr.prog.get() );
+					rmo_set_efn2data( pr.efn2.get() );
 					rmo_scan( pr.prog.get(), nullptr, seq, buf.data(), slen, comp, &oh );
 					std::vector<int32_t>	sh;
 					sim_scan( &dp, seq, buf.data(), slen, comp, sh );
@@ -155,6 +173,20 @@ int main( int argc, char **argv )
 							bad++;
 							break;
 						}
+						// efn2() sites: the device core, compiled for the host, against the oracle's value
+						for( int k = 0; pr.efn2 && k < dp.n_efn; k++ ){
+							if( dp.efn_sites[ k ].kind != RMA_EFN_KIND_EFN2 )
+								continue;
+							HostSeq	hs{ buf.data() };
+							const int	got = rme2_site_energy( &dp, pr.efn2.get(), &hs, sh.data() + h * stride, k );
+							const int	want = oh.data[ h * stride + n_cmp + k ];
+							n_efn2++;
+							if( got != want ){
+								if( bad < 10 )
+									fprintf( stderr, "seq %d comp %d hit %lld efn2 site %d: oracle %d, device core %d\n", seq, comp, ( long long )h, k, want, got );
+								bad++;
+							}
+						}
 					}
 					rmo_hits_free( &oh );
 				}
@@ -166,7 +198,10 @@ int main( int argc, char **argv )
 		fprintf( stderr, "stats: items %lld, rmd_next calls %lld, inner iterations %lld (ph0 ss %lld, ph0 other %lld), match_wchlx %lld\n",
 			rmd_stat[ 5 ], rmd_stat[ 0 ], rmd_stat[ 1 ], rmd_stat[ 2 ], rmd_stat[ 3 ], rmd_stat[ 4 ] );
 #endif
-		printf( "%s: %lld candidates, %lld mismatching strands\n", args.dfname.c_str(), ( long long )total, ( long long )bad );
+		printf( "%s: %lld candidates, %lld mismatching strands", args.dfname.c_str(), ( long long )total, ( long long )bad );
+		if( n_efn2 > 0 )
+			printf( " (%lld efn2 energies compared)", ( long long )n_efn2 );
+		printf( "\n" );
 		return bad ? 1 : 0;
 	}catch( rma::Error &e ){
 		fprintf( stderr, "%s\n", e.what() );

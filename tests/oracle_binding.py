@@ -42,6 +42,10 @@ def oracle_scan(descr, seqs, efn_dir=None):
         d = (efn_dir or os.environ.get("EFNDATA") or os.path.join(ROOT, "rnamotif_amd", "efndata")).encode()
         assert L.rmo_load_efndata(d, buf) == 1
         efn = C.cast(buf, C.c_void_p)
+    # efn2() sites: the tables as the product's loader read them (checked against the
+    # reference's efn2_drv in tests/test_efn2_oracle.py)
+    L.rmo_set_efn2data.argtypes = [C.c_void_p]
+    L.rmo_set_efn2data(getattr(descr, "efn2data", None))
     hits = RmoHits()
     L.rmo_hits_init(C.byref(hits), descr.program)
     for i, s in enumerate(seqs):

@@ -255,3 +255,36 @@ def test_mrnamotif_single_rank_equals_cli(built, workdir, gbrna, tmp_path):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert p.stdout == want
     assert b"complete descr length: min/max = 63/95" in p.stderr
+
+
+@pytest.mark.parametrize("name", ["trna.efn2.descr", "hairpin.efn2.descr"])
+def test_efn2_sites_equal_oracle(built, workdir, gbrna, name):
+    """efn2() on the device (rm_efn2_core.h: coaxial stacking, 1x1/2x1/2x2 interior loops from
+    global tables) beside efn(): every record, energies included, equals the oracle's."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    d = R.Descriptor(["-descr", os.path.join(ROOT, "tests", "data", name)])
+    assert d.efn2data
+    recs = R.read_fasta(gbrna)
+    seqs = [r[2] for r in recs][:4067 if name.startswith("trna") else 400]
+    sc = R.Scanner(d)
+    got = sc.scan(sc.database(seqs))
+    want = oracle_scan(d, seqs)
+    assert want.shape[0] > 1000
+    assert got.shape == want.shape and np.array_equal(got, want)
+    e2 = got[:, d.efn_off]
+    assert np.all(np.abs(e2) < 100000)          # closed structures: always defined
+
+
+def test_cli_efn2_equals_oracle_cli(built, workdir):
+    """The command line program with an efn2() score: same bytes as the oracle-backed program
+    (whose efn2 column is checked against the reference's efn2_drv in tests/test_efn2_oracle.py)."""
+    env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    descr = os.path.join(ROOT, "tests", "data", "trna.efn2.descr")
+    outs = []
+    for exe in (built["cli"], built["oracle_cli"]):
+        p = subprocess.run([exe, "-descr", descr, "gbrna.111.0.fastn"], cwd=workdir, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+        assert p.returncode == 0, p.stderr.decode()
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] and outs[0].count(b"\n>") == 1351

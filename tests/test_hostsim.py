@@ -16,9 +16,9 @@ def hostsim():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "hostsim", "hostsim_check.cpp")]
     srcs += [os.path.join(H, f) for f in ("rm_regex.cpp", "rm_compile.cpp", "rm_parse.cpp", "rm_score.cpp",
-                                          "rm_efndata.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp", "rm_dump.cpp", "rm_pack.cpp",
+                                          "rm_efndata.cpp", "rm_efn2data.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp", "rm_dump.cpp", "rm_pack.cpp",
                                           "rm_dev_program.cpp")]
-    srcs += [os.path.join(ROOT, "oracle", f) for f in ("rm_oracle_scan.c", "rm_oracle_efn.c")]
+    srcs += [os.path.join(ROOT, "oracle", f) for f in ("rm_oracle_scan.c", "rm_oracle_efn.c", "rm_oracle_efn2.c")]
     newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(H, "rm_scan_core.h")])
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < newest:
         subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + H,
@@ -39,3 +39,14 @@ def test_state_machine_equals_oracle(hostsim, workdir, args, ncand):
                        stderr=subprocess.PIPE, timeout=1800)
     assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
     assert (b"%d candidates, 0 mismatching strands" % ncand) in p.stdout
+
+
+def test_efn2_device_core_equals_oracle(hostsim, workdir):
+    """rm_efn2_core.h compiled for the host: the energy of every candidate of a cloverleaf
+    search (multi-branch loop, coaxial stacking) equals the oracle's restatement of RM_efn2."""
+    descr = os.path.join(ROOT, "tests", "data", "trna.efn2.descr")
+    env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    p = subprocess.run([hostsim, "-descr", descr, "gbrna.111.0.fastn"], cwd=workdir, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1800)
+    assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
+    assert b"1351 candidates, 0 mismatching strands (1351 efn2 energies compared)" in p.stdout
