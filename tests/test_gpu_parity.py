@@ -288,3 +288,46 @@ def test_cli_efn2_equals_oracle_cli(built, workdir):
         assert p.returncode == 0, p.stderr.decode()
         outs.append(p.stdout)
     assert outs[0] == outs[1] and outs[0].count(b"\n>") == 1351
+
+
+def _corpus():
+    d = os.path.join(ROOT, "tests", "golden", "descr")
+    return sorted(f for f in os.listdir(d) if f.endswith(".descr"))
+
+
+@pytest.mark.parametrize("name", _corpus())
+def test_descriptor_corpus_equals_oracle(built, gbrna, name):
+    """Every descriptor of the authors' descr/ corpus (parallel helices, triplexes, 4-plexes,
+    pseudoknots of all shapes, mismatches, pairfrac, sites, score programs): candidate records
+    on real and on random sequence equal the oracle's, or the descriptor is refused with a
+    message (syntax error by design: ps.3; beyond a documented device limit)."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    path = os.path.join(ROOT, "tests", "golden", "descr", name)
+    cwd = os.getcwd()
+    os.chdir(os.path.dirname(path))
+    try:
+        try:
+            d = R.Descriptor(["-descr", name])
+        except R.RnamotifError as e:
+            assert name in ("ps.3.descr", "rs.bad.descr", "rs.bad.2.descr") or "efn" in str(e), (name, str(e))
+            return
+    finally:
+        os.chdir(cwd)
+    try:
+        sc = R.Scanner(d)
+    except R.RnamotifError as e:
+        pytest.skip("refused by the device build: " + str(e))
+    rng = np.random.default_rng(31)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    recs = R.read_fasta(gbrna)
+    if d.maxlen > 1500:
+        # unbounded interiors (ss without maxlen under the 6000 base window): the search is
+        # quadratic in the window for the reference too -- minutes per kilobase -- so short entries
+        seqs = [r[2][:160] for r in recs[:6]] + [lut[rng.integers(0, 4, size=200)].tobytes()]
+    else:
+        seqs = [r[2] for r in recs[:150]] + [lut[rng.integers(0, 4, size=20_000)].tobytes()]
+    got = sc.scan(sc.database(seqs))
+    want = oracle_scan(d, seqs)
+    assert got.shape == want.shape, name
+    assert np.array_equal(got, want), name
