@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import os
 import sys
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 
@@ -47,26 +47,36 @@ def _records(path: str) -> List[Tuple[bytes, bytes, bytes]]:
     return R.read_fasta(path)
 
 
-def run(argv: Sequence[str], scan: Optional[Callable] = None, out_path: str = "-") -> int:
-    """argv: the rnamotif command line without the program name.  `scan` replaces
-    the GPU scanner in the CPU tests of the plumbing (tests/ only)."""
+def _scan_shard(descr, seqs, ranges, local_rank: int) -> np.ndarray:
+    """This rank's share on its GPU (rma_db_create_ranges + rma_scan)."""
+    if not seqs:
+        return np.zeros((0, descr.hit_stride), np.int32)
+    sc = R.Scanner(descr, device=local_rank)
+    return sc.scan(sc.database(seqs, ranges=ranges))
+
+
+def _init_process_group(world: int, local_rank: int):
+    """One process per GPU over RCCL; returns the device the gather uses."""
     import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("mrnamotif needs a GPU: the scan path has no CPU implementation")
+    if world == 1:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group(backend="nccl", device_id=dev)
+    return dev
+
+
+def run(argv: Sequence[str], out_path: str = "-") -> int:
+    """argv: the rnamotif command line without the program name."""
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    on_gpu = scan is None
-    if on_gpu and not torch.cuda.is_available():
-        raise SystemExit("mrnamotif needs a GPU: the scan path has no CPU implementation")
-    dev = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
-            torch.cuda.set_device(local_rank)
-            dev = torch.device("cuda", local_rank)
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend="gloo")
+    dev = _init_process_group(world, local_rank)
     rank = dist.get_rank() if world > 1 else 0
 
     if "-fmt" in argv and argv[list(argv).index("-fmt") + 1] != "fastn":
@@ -86,11 +96,7 @@ def run(argv: Sequence[str], scan: Optional[Callable] = None, out_path: str = "-
     mine = partition_ranges([len(r[2]) for r in recs], world)[rank]
     seqs = [recs[i][2] for i, _, _ in mine]
     ranges = [(lo, hi) for _, lo, hi in mine]
-    if on_gpu:
-        sc = R.Scanner(descr, device=local_rank)
-        hits = sc.scan(sc.database(seqs, ranges=ranges)) if seqs else np.zeros((0, descr.hit_stride), np.int32)
-    else:
-        hits = scan(descr, seqs, ranges)
+    hits = _scan_shard(descr, seqs, ranges, local_rank)
     if world > 1:
         hits = gather_hits(hits, [i for i, _, _ in mine], descr.hit_stride, device=dev)
     elif hits.shape[0]:

@@ -134,19 +134,29 @@ MRNAMOTIF_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 import numpy as np
+import torch.distributed as dist
 from rnamotif_amd import mrnamotif
 from oracle_binding import oracle_scan
 
-def cpu_scan(descr, seqs, ranges):
-    # stands in for Scanner.scan( database( seqs, ranges ) ) -- no GPU in this container
+# No GPU in this container: this TEST replaces the two device-bound pieces of the module
+# (process group over RCCL, the scan of a shard) to exercise everything around them --
+# reading, range partition, gather, ordering, replay.  The product has no such switch.
+def cpu_group(world, local_rank):
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    return None
+
+def cpu_scan(descr, seqs, ranges, local_rank):
     h = oracle_scan(descr, seqs)
     keep = np.zeros(h.shape[0], dtype=bool)
     for k, (lo, hi) in enumerate(ranges):
         keep |= (h[:, 0] == k) & (h[:, 2] >= lo) & (h[:, 2] < hi)
     return h[keep]
 
+mrnamotif._init_process_group = cpu_group
+mrnamotif._scan_shard = cpu_scan
 os.chdir(sys.argv[2])
-mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], scan=cpu_scan, out_path=sys.argv[4])
+mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], out_path=sys.argv[4])
 '''
 
 
