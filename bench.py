@@ -159,27 +159,15 @@ def main():
     dbs = [s.database(seqs) for s in scs]
     sc, db = scs[0], dbs[0]
 
+    from rnamotif_amd.distributed import gather_hits as gather_to_rank0
+    my_index = [rank * args.records + i for i in range(args.records)]   # entry numbers within the whole job
+
     def gather_hits(h, stride):
-        """Variable length gather of hit records to rank 0 (RCCL send/recv)."""
+        """Variable length gather of hit records to rank 0 over RCCL (rnamotif_amd/distributed.py,
+        the same function the world-size-2 gloo test runs)."""
         if world == 1:
             return h
-        n = torch.tensor([h.shape[0]], dtype=torch.int64, device=dev)
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, n)
-        counts = [int(c.item()) for c in counts]
-        if rank == 0:
-            parts = [h]
-            for r in range(1, world):
-                buf = torch.empty((counts[r], stride), dtype=torch.int32, device=dev)
-                if counts[r]:
-                    dist.recv(buf, src=r)
-                part = buf.cpu().numpy()
-                part[:, 0] += r * args.records          # sequence index within the whole job
-                parts.append(part)
-            return np.concatenate(parts, axis=0)
-        if h.shape[0]:
-            dist.send(torch.from_numpy(h).to(dev), dst=0)
-        return h
+        return gather_to_rank0(h, my_index, stride, device=dev)
 
     def step():
         n = 0
