@@ -395,6 +395,10 @@ struct rme_cand_t {
 	const Seq	*sq;
 	int	idx, idx2, pos, pos2;	// pos2 resolved (last base of idx2 included)
 	int	off5, start, len;
+	// optional per-candidate arrays (the kernel keeps them in LDS for calls of up to
+	// RME_CACHE bases): what setupefn() materialises as rm_bcseq[] / rm_basepr[]
+	int16_t	*cbp = nullptr;
+	uint8_t	*cbc = nullptr;
 
 	RMD_FN_MEMBER int	moff( int d ) const { return w[ RMA_HIT_HDR + 4 * d ]; }
 	RMD_FN_MEMBER int	mlen( int d ) const { return w[ RMA_HIT_HDR + 4 * d + 1 ]; }
@@ -437,16 +441,46 @@ struct rme_cand_t {
 		}
 		return 1;
 	}
+	// fill cbc[] / cbp[] for the whole call: one pass over the elements
+	RMD_FN_MEMBER void	fill_cache( int16_t *bpbuf, uint8_t *bcbuf )
+	{
+		for( int d = idx; d <= idx2; d++ ){
+			const rmd_elem_t	&st = P->elems[ d ];
+			const int	p0 = d == idx ? pos : 0, p1 = d == idx2 ? pos2 + 1 : mlen( d );
+			const bool	ss = st.type == RMA_T_SS || ( st.type == RMA_T_H5 && d == idx2 ) || ( st.type == RMA_T_H3 && d == idx );
+			const int	m = st.mates[ 0 ];
+			const int	ps = P->efn_usestdbp ? P->efn_stdbp : st.pairset;
+			for( int pq = p0; pq < p1; pq++ ){
+				const int	p = moff( d ) + pq, i = p - start;
+				const int	b = sq->code( p );
+				bcbuf[ i ] = uint8_t( b );
+				int	partner = -1;
+				if( !ss ){
+					const int	q1 = mlen( m ) - pq - 1;
+					const int	b1 = sq->code( q1 + moff( m ) );
+					if( ( rmd_pairsets( P )[ ps ].mat2 >> ( b * 5 + b1 ) ) & 1 )
+						partner = q1 + moff( m ) - off5;
+				}
+				bpbuf[ i ] = int16_t( partner );
+			}
+		}
+		cbp = bpbuf;
+		cbc = bcbuf;
+	}
 	RMD_FN_MEMBER int	bc( int i ) const
 	{
 		if( i < 0 || i >= len )
 			return RMA_BC_N;	// the reference reads stale rm_bcseq[] there; never reached for nested helices
+		if( cbc != nullptr )
+			return cbc[ i ];
 		return sq->code( start + i );
 	}
 	RMD_FN_MEMBER int	bp( int i ) const
 	{
 		if( i < 0 || i >= len )
 			return -1;
+		if( cbp != nullptr )
+			return cbp[ i ];
 		int	p = start + i;
 		for( int d = idx; d <= idx2; d++ ){
 			int	o = moff( d ), l = mlen( d );
@@ -468,8 +502,10 @@ struct rme_cand_t {
 
 // Energy of efn site k for the hit record w; what do_sc_efnx() returns before
 // the 0.01 scaling (score.c:1672-1679).
+#define RME_CACHE	192	// longest call whose base and pair arrays the kernel keeps in LDS
 template< class Seq >
-RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const Seq *sq, const int32_t *w, int k )
+RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const Seq *sq, const int32_t *w, int k,
+	int16_t *bpbuf = nullptr, uint8_t *bcbuf = nullptr )
 {
 	rme_cand_t<Seq>	c;
 	c.P = P;
@@ -477,6 +513,8 @@ RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const
 	c.sq = sq;
 	if( !c.setup( P->efn_sites[ k ] ) )
 		return RME_INF;
+	if( bpbuf != nullptr && c.len <= RME_CACHE )
+		c.fill_cache( bpbuf, bcbuf );
 	rme_ctx_t< rme_cand_t<Seq> >	x;
 	x.T = T;
 	x.C = &c;

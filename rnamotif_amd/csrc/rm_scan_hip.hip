@@ -531,28 +531,35 @@ struct DevSeq {
 	__device__ inline int code( int p ) const { return db_strand_code( db, off, slen, comp, p ); }
 };
 
+#define RME_N16_PAD	( ( RME_N16 + 7 ) / 8 * 8 )
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK )
 rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
 	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc, const rma_efn2data_t *e2 )
 {
-	__shared__ int16_t	t16[ RME_N16 ];
+	// tables staged 16 bytes per lane and step (the device copy is padded to a multiple of 8 entries)
+	__shared__ __align__( 16 ) int16_t	t16[ RME_N16_PAD ];
 	if( g16 != nullptr )
-		for( int i = threadIdx.x; i < RME_N16; i += BLOCK )
-			t16[ i ] = g16[ i ];
+		for( int i = threadIdx.x; i < RME_N16_PAD / 8; i += BLOCK )
+			reinterpret_cast<uint4 *>( t16 )[ i ] = reinterpret_cast<const uint4 *>( g16 )[ i ];
 	__syncthreads();
+	// per lane: base codes and partners of the call, when it is short enough
+	__shared__ int16_t	s_bp[ BLOCK ][ RME_CACHE + 1 ];
+	__shared__ uint8_t	s_bc[ BLOCK ][ RME_CACHE + 4 ];
 	long long	h = ( long long )blockIdx.x * BLOCK + threadIdx.x;
 	if( h >= n_hits )
 		return;
 	rme_tables_t	T{ t16, tlkey, loginc };
+	int16_t	*bpbuf = s_bp[ threadIdx.x ];
+	uint8_t	*bcbuf = s_bc[ threadIdx.x ];
 	int32_t	*w = hits + h * gP->hit_stride;
 	DevSeq	sq{ db, db.base_off[ w[ 0 ] ], db.slen[ w[ 0 ] ], w[ 1 ] };
 	const int	efn_off = RMA_HIT_HDR + 4 * gP->n_elems + 4;
 	for( int k = 0; k < gP->n_efn; k++ ){
 		if( gP->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
-			w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy( gP, e2, &sq, w, k ) : RME2_INF;
+			w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy( gP, e2, &sq, w, k, bpbuf, bcbuf ) : RME2_INF;
 		else if( g16 != nullptr )
-			w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k );
+			w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k, bpbuf, bcbuf );
 	}
 }
 
@@ -595,7 +602,7 @@ struct rma_db {
 
 static void build_tables16( const rma_efndata_t *ed, std::vector<int16_t> &t16, std::vector<int32_t> &tlkey )
 {
-	t16.assign( RME_N16, 0 );
+	t16.assign( ( RME_N16 + 7 ) / 8 * 8, 0 );	// padded for 16-byte staging loads
 	tlkey.assign( 100, -1 );
 	auto put = [&]( int off, const int32_t *src, int n ){
 		for( int i = 0; i < n; i++ ){
