@@ -1005,19 +1005,20 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 	HIPCHK( hipMemcpyAsync( sc->h_raw, sc->d_hits, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
 	HIPCHK( hipStreamSynchronize( sc->stream ) );
 	// reference order: (seq, comp, szero, rank, order)
-	std::vector<int64_t>	idx( n );
-	std::iota( idx.begin(), idx.end(), 0 );
+	// the five header words (all >= 0) as two 64-bit keys
+	struct Key { uint64_t a, b; int64_t i; };
 	const int32_t	*d = sc->h_raw;
-	std::sort( idx.begin(), idx.end(), [ & ]( int64_t a, int64_t b ){
-		const int32_t	*x = d + a * stride, *y = d + b * stride;
-		for( int k = 0; k < RMA_HIT_HDR; k++ )
-			if( x[ k ] != y[ k ] )
-				return x[ k ] < y[ k ];
-		return false;
-	} );
+	std::vector<Key>	keys( static_cast<size_t>( n ) );
+	for( int64_t i = 0; i < n; i++ ){
+		const int32_t	*x = d + i * stride;
+		keys[ i ].a = ( uint64_t( uint32_t( x[ 0 ] ) ) << 32 ) | ( uint64_t( uint32_t( x[ 1 ] ) & 1u ) << 31 ) | uint32_t( x[ 2 ] );
+		keys[ i ].b = ( uint64_t( uint32_t( x[ 3 ] ) ) << 32 ) | uint32_t( x[ 4 ] );
+		keys[ i ].i = i;
+	}
+	std::sort( keys.begin(), keys.end(), []( const Key &x, const Key &y ){ return x.a != y.a ? x.a < y.a : x.b < y.b; } );
 	sc->h_sorted.resize( words );
 	for( int64_t i = 0; i < n; i++ )
-		memcpy( &sc->h_sorted[ size_t( i ) * stride ], d + idx[ i ] * stride, stride * sizeof( int32_t ) );
+		memcpy( &sc->h_sorted[ size_t( i ) * stride ], d + keys[ i ].i * stride, stride * sizeof( int32_t ) );
 	*hits = sc->h_sorted.data();
 	return 0;
 }
