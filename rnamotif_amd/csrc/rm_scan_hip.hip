@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -986,8 +987,18 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 {
 	*hits = nullptr;
 	int64_t	n = 0;
+	const bool	timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
+	auto	t0 = std::chrono::steady_clock::now();
+	auto lap = [&]( const char *what ){
+		if( timing ){
+			auto	t1 = std::chrono::steady_clock::now();
+			fprintf( stderr, "[timing] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+			t0 = t1;
+		}
+	};
 	if( rma_scan_device( sc, db, &n, nullptr, nullptr, err, errlen ) )
 		return 1;
+	lap( "kernels" );
 	*n_hits = n;
 	if( n == 0 )
 		return 0;
@@ -1004,6 +1015,7 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 	}
 	HIPCHK( hipMemcpyAsync( sc->h_raw, sc->d_hits, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
 	HIPCHK( hipStreamSynchronize( sc->stream ) );
+	lap( "copy back" );
 	// reference order: (seq, comp, szero, rank, order)
 	// the five header words (all >= 0) as two 64-bit keys
 	struct Key { uint64_t a, b; int64_t i; };
@@ -1019,6 +1031,7 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 	sc->h_sorted.resize( words );
 	for( int64_t i = 0; i < n; i++ )
 		memcpy( &sc->h_sorted[ size_t( i ) * stride ], d + keys[ i ].i * stride, stride * sizeof( int32_t ) );
+	lap( "ordering" );
 	*hits = sc->h_sorted.data();
 	return 0;
 }
