@@ -76,23 +76,37 @@ def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int
     if h.shape[0]:
         h[:, 0] = np.asarray(global_index, dtype=np.int32)[h[:, 0]]
     dev = device if device is not None else torch.device("cpu")
+    # one collective for the counts, one host sync
     n = torch.tensor([h.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    all_n = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_n, n)
+    counts = [int(c) for c in all_n.tolist()]
     if rank == 0:
-        parts = [h]
+        # post every receive, then wait: the transfers of the ranks overlap (xGMI is point to point)
+        bufs, reqs = {}, []
         for r in range(1, world):
             if counts[r] == 0:
                 continue
-            buf = torch.empty((counts[r], stride), dtype=torch.int32, device=dev)
-            dist.recv(buf, src=r)
-            parts.append(buf.cpu().numpy())
-        allh = np.concatenate(parts, axis=0) if parts else h
-        if allh.shape[0] > 1:
-            order = np.lexsort(allh[:, :5].T[::-1])
-            allh = allh[order]
-        return allh
+            bufs[r] = torch.empty((counts[r], stride), dtype=torch.int32, device=dev)
+            reqs.append(dist.irecv(bufs[r], src=r))
+        for q in reqs:
+            q.wait()
+        parts = [h] + [bufs[r].cpu().numpy() for r in sorted(bufs)]
+        allh = np.concatenate(parts, axis=0) if len(parts) > 1 else h
+        return sort_hits(allh)
     if h.shape[0]:
         dist.send(torch.from_numpy(h).to(dev), dst=0)
     return np.zeros((0, stride), dtype=np.int32)
+
+
+def sort_hits(allh: np.ndarray) -> np.ndarray:
+    """Records by (seq, comp, szero, rank, order) = the reference's output order.  Ranks that
+    hold consecutive runs of entries deliver an already ordered concatenation: checked first."""
+    if allh.shape[0] < 2:
+        return allh
+    k = allh[:, :5].astype(np.uint64)
+    a = (k[:, 0] << np.uint64(32)) | ((k[:, 1] & np.uint64(1)) << np.uint64(31)) | k[:, 2]
+    b = (k[:, 3] << np.uint64(32)) | k[:, 4]
+    if bool(np.all((a[1:] > a[:-1]) | ((a[1:] == a[:-1]) & (b[1:] >= b[:-1])))):
+        return allh
+    return allh[np.lexsort((b, a))]

@@ -20,7 +20,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 import rnamotif_amd as R
-from rnamotif_amd.distributed import gather_hits, partition_ranges
+from rnamotif_amd.distributed import gather_hits, partition_ranges, sort_hits
 
 _VALUE_OPTS = {"-descr", "-xdescr", "-xdfname", "-N", "-fmt"}
 
@@ -102,7 +102,7 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
     elif hits.shape[0]:
         hits = hits.copy()
         hits[:, 0] = np.asarray([i for i, _, _ in mine], dtype=np.int32)[hits[:, 0]]
-        hits = hits[np.lexsort(hits[:, :5].T[::-1])]
+        hits = sort_hits(hits)
     if rank == 0:
         rp = R.Replay(descr, out_path)
         rp.batch([r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], hits)
