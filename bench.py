@@ -61,6 +61,30 @@ def profiled_traffic(kernel="rma_search_kernel"):
     return int(2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024)
 
 
+def profiled_issue(kernel_ms, kernel="rma_search_kernel"):
+    """The bound that does apply: instruction issue.  VALU wave-instructions per launch from
+    the committed PMC pass over this workload (SQ_INSTS_VALU) divided by the kernel time
+    measured now, against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per 64-wide VALU instruction;
+    lanes = average active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_final3_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    c = {}
+    for r in csv.DictReader(open(path)):
+        if kernel in r["kernel"]:
+            c[r["counter"]] = float(r["mean_per_dispatch"])
+    if "SQ_INSTS_VALU" not in c:
+        return None
+    peak = 256 * 4 * 2.4e9 / 4 / 1e9
+    ach = c["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+           "frac": round(ach / peak, 4), "salu_per_valu": round(c.get("SQ_INSTS_SALU", 0) / c["SQ_INSTS_VALU"], 3)}
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+        out["active_lanes_of_64"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 1)
+    return out
+
+
 def cpu_baseline(descr, seqs, budget_bases):
     """The scalar CPU oracle (kind 'port': byte-identical to the reference on
     its golden tests, and within a few percent of its speed here) on a bounded
@@ -251,6 +275,7 @@ def main():
                 "kernel_ms": round(search_ms, 3),
                 "efn_kernel_ms": round(efn_ms, 3),
                 "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE,
+                "secondary": profiled_issue(search_ms) if default_workload and world == 1 else None,
                 "note": "the search is integer/LDS issue bound, not HBM bound (SURVEY.md 8d); "
                         "kernel-only rate = %.1f Mbases/s" % (bases_per_gpu * len(descrs) / (search_ms * 1e-3) / 1e6),
             },

@@ -331,3 +331,44 @@ def test_descriptor_corpus_equals_oracle(built, gbrna, name):
     want = oracle_scan(d, seqs)
     assert got.shape == want.shape, name
     assert np.array_equal(got, want), name
+
+
+def test_n_rich_synthetic_equals_oracle(built, workdir):
+    """the synthetic database with 2.7 % N (gbrna-like) -- the ambiguity
+    mask path at scale, both strands."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(27)
+    lut = np.frombuffer(b"acgtn", dtype=np.uint8)
+    seqs = []
+    for n in (1_500_000, 65_537):
+        v = rng.integers(0, 4, size=n)
+        v[rng.random(n) < 0.027] = 4
+        seqs.append(lut[v].tobytes())
+    for name in ("trna.descr", "mp.ends.descr"):
+        d = _descr(workdir, name)
+        sc = R.Scanner(d)
+        got = sc.scan(sc.database(seqs))
+        want = oracle_scan(d, seqs)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+
+
+def test_one_long_entry(built, workdir):
+    """A single 12 Mbase entry (coordinates far beyond 16 bits, thousands of tiles): the
+    whole-entry scan equals the union of three start-position slices of it, and every record
+    is self-consistent."""
+    import rnamotif_amd as R
+    rng = np.random.default_rng(28)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    seq = lut[rng.integers(0, 4, size=12_000_000)].tobytes()
+    d = _descr(workdir, "trna.descr")
+    sc = R.Scanner(d)
+    whole = sc.scan(sc.database([seq]))
+    parts = [sc.scan(sc.database([seq], ranges=[(lo, hi)])) for lo, hi in ((0, 4_000_001), (4_000_001, 11_999_000), (11_999_000, 12_000_000))]
+    allh = np.concatenate(parts, axis=0)
+    allh = allh[np.lexsort(allh[:, :5].T[::-1])]
+    assert whole.shape[0] > 300 and np.array_equal(allh, whole)
+    off = whole[:, 5::4][:, :d.n_elems]
+    ln = whole[:, 6::4][:, :d.n_elems]
+    assert np.all(off[:, 1:] == off[:, :-1] + ln[:, :-1]) and np.all(off[:, 0] == whole[:, 2])
+    assert whole[:, 2].max() > 11_000_000 and np.all(off[:, -1] + ln[:, -1] <= len(seq))
