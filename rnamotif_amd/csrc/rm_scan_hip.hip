@@ -111,13 +111,13 @@ struct LdsRecs {
 #endif
 template< int BLOCK, bool LEAN >
 __global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES_PER_SIMD )
-rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb, int tile_bytes, int dbg )
+rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
 	// gP is the compact image (rmd_make_image): prog_bytes of it, a multiple of 16
 	unsigned	*queue = reinterpret_cast<unsigned *>( smem + prog_bytes );
-	uint8_t	*tile = smem + prog_bytes + QCAP * sizeof( unsigned );
+	uint8_t	*tile = smem + prog_bytes + qcap * sizeof( unsigned );
 	__shared__ long long	s_tile;
 	__shared__ int	s_seq, s_qn, s_qhead;
 	const int	tid = threadIdx.x;
@@ -147,7 +147,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 	const bool	e0_at_szero = e0.type == RMA_T_P5 || e0.type == RMA_T_T1 || e0.type == RMA_T_Q1 ||
 		( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
 	const int	pb_words = ( tile_bytes + 63 ) / 64 + 3;
-	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + prog_bytes + QCAP * sizeof( unsigned ) +
+	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + prog_bytes + qcap * sizeof( unsigned ) +
 		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
 	unsigned long long	*occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
 	rmd_lrec_t	*lean = reinterpret_cast<rmd_lrec_t *>( occ + pb_words );
@@ -255,7 +255,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 			base_ = __shfl( base_, __ffsll( m_ ) - 1 ); \
 			if( pred ){ \
 				const int	slot_ = base_ + __popcll( m_ & lt_mask ); \
-				if( slot_ < QCAP ) \
+				if( slot_ < qcap ) \
 					queue[ slot_ ] = ( item ); \
 				else if constexpr( LEAN ){ \
 					rmd_lean_t	st_; \
@@ -447,7 +447,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb
 		// that finishes its item pops the next one at once (wave-aggregated pop), so a
 		// wave lasts as long as its share of the work, not as its slowest item times
 		// the number of rounds.
-		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < QCAP ? s_qn : QCAP );
+		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < qcap ? s_qn : qcap );
 		if( ( dbg & 2 ) && tid == 0 )
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
 		int	k = -1;
@@ -578,6 +578,7 @@ struct rma_scanner {
 	bool	need_efn2 = false;
 	rmd_program_t	*d_prog = nullptr;	// compact image, prog_bytes long
 	int	prog_bytes = 0;
+	int	qcap = QCAP;		// work queue entries per workgroup
 	int16_t	*d_t16 = nullptr;
 	int32_t	*d_tlkey = nullptr, *d_loginc = nullptr;
 	bool	have_efn = false;
@@ -648,11 +649,11 @@ extern "C" int rma_device_count( void )
 }
 
 // LDS of one search workgroup: program image | queue | tile | 6 bit vectors | lean records
-static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean )
+static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap )
 {
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
 	const size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
-	size_t	lds = size_t( prog_bytes ) + QCAP * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
+	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
 	if( lean )
 		lds += size_t( dp.n_searches ) * 256 * sizeof( rmd_lrec_t );
 	return lds;
@@ -721,11 +722,21 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		// and 6.9 again at 8192 where only three fit).
 		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 256;
 		for( int t = 8192; t >= 2048; t -= 512 )
-			if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true ) <= budget ){
+			if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true, sc->qcap ) <= budget ){
 				sc->tile_t = t;
 				break;
 			}
 	}
+	if( !sc->dprog.lean_ok ){
+		// general instance: LDS is not what limits it (frames live in scratch), so larger
+		// tiles and a queue that holds their items (pk1 41.9 -> 32 ms, qu+tr 94 -> 87 ms at
+		// 4096; at 8192 a 1024-entry queue overflows into the in-place search: 175 ms)
+		sc->tile_t = 4096;
+		sc->qcap = 4096;
+	}
+	if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )
+		if( atoi( qq ) >= 64 && atoi( qq ) <= 16384 )
+			sc->qcap = atoi( qq );
 	const char	*tt = getenv( "RNAMOTIF_TILE" );
 	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 16384 )
 		sc->tile_t = atoi( tt );
@@ -922,7 +933,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	const int	dbg = getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0;
 	const bool	lean = dp.lean_ok && !( dbg & 16 );
 	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	size_t	lds = search_lds_bytes( sc->prog_bytes, dp, sc->tile_t, lean );
+	size_t	lds = search_lds_bytes( sc->prog_bytes, dp, sc->tile_t, lean, sc->qcap );
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;
@@ -938,10 +949,10 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		if( lean )
 			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, sc->prog_bytes, v, hb, tile_bytes, dbg );
+				sc->d_prog, sc->prog_bytes, sc->qcap, v, hb, tile_bytes, dbg );
 		else
 			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, false> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, sc->prog_bytes, v, hb, tile_bytes, dbg );
+				sc->d_prog, sc->prog_bytes, sc->qcap, v, hb, tile_bytes, dbg );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );
