@@ -1158,21 +1158,6 @@ RMD_FN bool rmd_tail_ok( const rmd_program_t *P, const rmd_elem_t &stp, const rm
 	return false;
 }
 
-// Level 0 in the pre-filter: the helix length is not known yet -- any length will do.
-RMD_FN bool rmd_tail_any( const rmd_program_t *P, const rmd_elem_t &stp, const rmd_seq_t &sq, int szero, int sd )
-{
-	if( stp.tail_s < 0 )
-		return true;
-	for( int hl = stp.minlen; hl <= stp.maxlen; hl++ ){
-		const int	ilen = sd - szero + 1 - 2 * hl;
-		if( ilen < stp.minilen )
-			break;
-		if( ilen <= stp.maxilen && rmd_tail_ok( P, stp, sq, szero, hl, sd - szero - hl ) )
-			return true;
-	}
-	return false;
-}
-
 RMD_FN rmd_lrec_t rmd_lean_open( const rmd_program_t *P, int level, int zero, int osd )	// rmd_enter()
 {
 	const rmd_elem_t	&stp = P->elems[ P->searches[ level ] ];

@@ -92,12 +92,6 @@ struct LdsRecs {
 };
 
 // ---------------------------------------------------------------- search kernel
-#ifndef LEVEL_VOTE
-#define LEVEL_VOTE	0
-#endif
-#ifndef LEVEL_TIE
-#define LEVEL_TIE	&& c > 0
-#endif
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
 #endif
@@ -455,7 +449,6 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		if constexpr( LEAN ){
 			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
 			rmd_lean_t	st;
-			[[maybe_unused]] const int	n_lv = P->n_searches;
 			for( ; ; ){
 				const unsigned long long	want = __ballot( k < 0 && !dry );
 				if( want ){
@@ -476,25 +469,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 				if( __ballot( k >= 0 ) == 0 )
 					break;
-#if LEVEL_VOTE
-				// Lanes of a wave sit at different levels of different items.  Serve one
-				// level per round -- the most populated one (ties: the deepest) -- so that the
-				// element type and its loop bounds are uniform across the active lanes; the
-				// others wait and are joined by lanes that arrive at their level.
-				int	best = 0, best_n = -1;
-				for( int lv = 0; lv < n_lv; lv++ ){
-					const int	c = __popcll( __ballot( k == lv ) );
-					if( c >= best_n LEVEL_TIE ){
-						best_n = c;
-						best = lv;
-					}
-				}
-				if( k == best )
-					k = rmd_lean_step( P, lr, st, sq, best, &lane, sink );
-#else
 				if( k >= 0 )
 					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink );
-#endif
 			}
 		}else
 		for( ; ; ){
