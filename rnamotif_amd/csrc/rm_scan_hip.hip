@@ -195,6 +195,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		for( int p = p_from + tid; p < p_to; p += BLOCK )
 			tile[ p - p_lo ] = uint8_t( db_strand_code( db, off, slen, comp, p ) );
 		__syncthreads();
+		// short entries fill only part of a tile: the loops below run over what is there
+		const int	pos_end = rmd_imin( slen - P->dminlen + 1, pos_hi );
+		const int	n_pos = rmd_imin( T, pos_end - z0 );			// start positions of this tile
+		const int	vec_words = rmd_imin( pb_words, ( p_to - p_lo + 64 + 63 ) / 64 + 1 );	// bit vector words in use
 
 		// ---- pass A: pre-filter.  Where the first search element is a proper helix
 		// or a 4-plex, almost every (start, end) pair dies at its first base pairs
@@ -211,7 +215,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		if( lit ){
 			const rmd_regex_t	&lre = rmd_regexes( P )[ P->lit_re ];
 			const int	n_valid = p_to - p_lo;
-			for( int base = ( tid >> 6 ) * 64; base < pb_words * 64; base += BLOCK ){
+			for( int base = ( tid >> 6 ) * 64; base < vec_words * 64; base += BLOCK ){
 				const int	q = base + lane_id - 64;
 				bool	ok = q >= p_from - p_lo && q + lit_n <= n_valid;
 				for( int jj = 0; ok && jj < lit_n; jj++ )
@@ -267,7 +271,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			// (start, end) all pair" is an AND of minlen shifted 64-bit windows, 64 end
 			// positions at a time.
 			const int	n_valid = p_to - p_lo;
-			for( int base = ( tid >> 6 ) * 64; base < pb_words * 64; base += BLOCK ){
+			for( int base = ( tid >> 6 ) * 64; base < vec_words * 64; base += BLOCK ){
 				const int	q = base + lane_id - 64;		// one pad word in front
 				const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
 				for( int b5 = 0; b5 < 5; b5++ ){
@@ -332,7 +336,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					W = imin >= 64 ? 0 : W & ( ~0ull << imin );
 				return W;
 			};
-			for( int j = 0; j < T; j += BLOCK ){
+			for( int j = 0; j < n_pos; j += BLOCK ){
 				const int	rel = j + tid;
 				const int	szero = z0 + rel;
 				bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
@@ -388,7 +392,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 			}
 		}else
-		for( int j = 0; j < T; j += BLOCK ){
+		for( int j = 0; j < n_pos; j += BLOCK ){
 			const int	rel = j + tid;
 			const int	szero = z0 + rel;
 			bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
