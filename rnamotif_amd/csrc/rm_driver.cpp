@@ -218,7 +218,7 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 			st.n_seqs++;
 			st.n_bases += int64_t( rec.seq.size() );
 			in_batch += int64_t( rec.seq.size() );
-			batch.push_back( rec );
+			batch.push_back( std::move( rec ) );
 			if( in_batch >= batch_bases )
 				flush();
 		}

@@ -5,14 +5,8 @@
 
 namespace rma {
 
-static int skipbl2nl( FILE *fp )	// dbutil.c:336-345
-{
-	int	c;
-	while( isspace( c = getc( fp ) ) )
-		if( c == '\n' )
-			break;
-	return c;
-}
+// skipbl2nl(), dbutil.c:336-345, over the reader's own get()
+#define SKIPBL2NL( c_ )	do{ while( isspace( ( c_ ) = get() ) ) if( ( c_ ) == '\n' ) break; }while( 0 )
 
 SeqFormat seq_format_of( const std::string &name )
 {
@@ -32,27 +26,49 @@ bool FastaReader::next( SeqRecord &rec )
 	}
 }
 
-// Sequence letters up to the next '>' (FN_/PIR_fgetseq share this loop, dbutil.c:104-126,197-223)
-static void read_letters( FILE *fp, const char *who, int maxslen, SeqRecord &rec )
+// Sequence letters up to the next '>' (FN_/PIR_fgetseq share this loop, dbutil.c:104-126,197-223):
+// every alphabetic character, lower case, u -> t; straight over the block buffer
+void FastaReader::read_letters( const char *who, SeqRecord &rec )
 {
-	unsigned	cnt = 0;
-	int	c;
-	while( ( c = getc( fp ) ) != EOF ){
-		if( c == '>' ){
-			ungetc( c, fp );
-			break;
+	static unsigned char	tab[ 256 ];
+	static bool	init = false;
+	if( !init ){
+		for( int c = 0; c < 256; c++ ){
+			int	l = isalpha( c ) ? tolower( c ) : 0;
+			tab[ c ] = ( unsigned char )( l == 'u' ? 't' : l );
 		}
-		if( isalpha( c ) ){
-			cnt++;
-			if( cnt < unsigned( maxslen ) ){
-				c = tolower( c );
-				rec.seq.push_back( c == 'u' ? 't' : char( c ) );
+		init = true;
+	}
+	unsigned	cnt = 0;
+	const unsigned	lim = unsigned( maxslen_ );
+	for( bool more = true; more; ){
+		if( pos_ == len_ ){
+			len_ = fread( buf_.data(), 1, buf_.size(), fp_ );
+			pos_ = 0;
+			if( len_ == 0 )
+				break;
+		}
+		const char	*p = buf_.data() + pos_, *e = buf_.data() + len_;
+		const size_t	o0 = rec.seq.size();
+		rec.seq.resize( o0 + size_t( e - p ) );
+		char	*o = &rec.seq[ o0 ];
+		for( ; p < e; p++ ){
+			const unsigned char	t = tab[ ( unsigned char )*p ];
+			if( t ){
+				cnt++;
+				if( cnt < lim )
+					*o++ = char( t );
+			}else if( *p == '>' ){
+				more = false;
+				break;
 			}
 		}
+		rec.seq.resize( size_t( o - rec.seq.data() ) );
+		pos_ = size_t( p - buf_.data() );	// at the '>' (left unread) or at the end of the block
 	}
-	if( cnt > unsigned( maxslen ) )
+	if( cnt > lim )
 		fprintf( stderr, "%s: entry: '%s': seq len: %d, truncated to %d.\n",
-			who, rec.sid.c_str(), cnt, maxslen - 1 );
+			who, rec.sid.c_str(), cnt, maxslen_ - 1 );
 }
 
 bool FastaReader::next_pir( SeqRecord &rec )	// PIR_fgetseq, dbutil.c:130-224
@@ -61,19 +77,20 @@ bool FastaReader::next_pir( SeqRecord &rec )	// PIR_fgetseq, dbutil.c:130-224
 	rec.sdef.clear();
 	rec.seq.clear();
 	rec.eof = true;
-	int	c = getc( fp_ );
+	int	c = get();
 	if( c == EOF )
 		return false;
 	if( c != '>' ){
 		fprintf( stderr, "PIR_fgetseq: pir file does not begin with '>'.\n" );
 		return false;
 	}
-	if( ( c = skipbl2nl( fp_ ) ) == EOF || c == '\n' ){
+	SKIPBL2NL( c );
+	if( c == EOF || c == '\n' ){
 		fprintf( stderr, "PIR_fgetseq: pir file has an unnamed entry.\n" );
 		return false;
 	}
 	rec.sid.push_back( char( c ) );
-	while( ( c = getc( fp_ ) ) != EOF ){
+	while( ( c = get() ) != EOF ){
 		if( isspace( c ) )
 			break;
 		if( rec.sid.size() < 99 )
@@ -85,7 +102,7 @@ bool FastaReader::next_pir( SeqRecord &rec )	// PIR_fgetseq, dbutil.c:130-224
 	}
 	if( c != '\n' ){
 		fprintf( stderr, "PIR_fgetseq: entry: '%s': extra chars on ID line ignored.\n", rec.sid.c_str() );
-		while( ( c = getc( fp_ ) ) != EOF )
+		while( ( c = get() ) != EOF )
 			if( c == '\n' )
 				break;
 	}
@@ -96,10 +113,10 @@ bool FastaReader::next_pir( SeqRecord &rec )	// PIR_fgetseq, dbutil.c:130-224
 	// the title line: its first character is taken whatever it is (dbutil.c:181-183)
 	const unsigned	s_sdef = 20000;
 	unsigned	cnt = 1;
-	c = getc( fp_ );
+	c = get();
 	if( c != EOF )		// (a newline too: an empty title line swallows the line after it)
 		rec.sdef.push_back( char( c ) );
-	while( ( c = getc( fp_ ) ) != 0 ){
+	while( ( c = get() ) != 0 ){
 		if( c == '\n' || c == EOF )
 			break;
 		cnt++;
@@ -110,7 +127,7 @@ bool FastaReader::next_pir( SeqRecord &rec )	// PIR_fgetseq, dbutil.c:130-224
 		fprintf( stderr, "PIR_fgetseq: entry: '%s': title len: %d, truncated to %d.\n",
 			rec.sid.c_str(), cnt, s_sdef - 1 );
 	rec.eof = false;
-	read_letters( fp_, "PIR_fgetseq", maxslen_, rec );
+	read_letters( "PIR_fgetseq", rec );
 	return true;
 }
 
@@ -209,7 +226,7 @@ bool FastaReader::next_fastn( SeqRecord &rec )	// FN_fgetseq, dbutil.c:42-128
 	rec.sdef.clear();
 	rec.seq.clear();
 	rec.eof = false;
-	int	c = getc( fp_ );
+	int	c = get();
 	if( c == EOF ){
 		rec.eof = true;
 		return false;
@@ -219,13 +236,14 @@ bool FastaReader::next_fastn( SeqRecord &rec )	// FN_fgetseq, dbutil.c:42-128
 		rec.eof = true;
 		return false;
 	}
-	if( ( c = skipbl2nl( fp_ ) ) == EOF || c == '\n' ){
+	SKIPBL2NL( c );
+	if( c == EOF || c == '\n' ){
 		fprintf( stderr, "FN_fgetseq: fastn file has an unnamed entry.\n" );
 		rec.eof = true;
 		return false;
 	}
 	rec.sid.push_back( char( c ) );
-	while( ( c = getc( fp_ ) ) != EOF ){
+	while( ( c = get() ) != EOF ){
 		if( isspace( c ) )
 			break;
 		if( rec.sid.size() < 99 )	// SID_SIZE; the reference does not check
@@ -234,14 +252,15 @@ bool FastaReader::next_fastn( SeqRecord &rec )	// FN_fgetseq, dbutil.c:42-128
 	if( c == EOF )
 		return true;
 	if( c != '\n' ){
-		if( ( c = skipbl2nl( fp_ ) ) == EOF )
+		SKIPBL2NL( c );
+		if( c == EOF )
 			return true;
 	}
 	if( c != '\n' ){
 		const unsigned	s_sdef = 20000;		// SDEF_SIZE
 		unsigned	cnt = 1;
 		rec.sdef.push_back( char( c ) );
-		while( ( c = getc( fp_ ) ) != 0 ){
+		while( ( c = get() ) != 0 ){
 			if( c == '\n' || c == EOF )
 				break;
 			cnt++;
@@ -254,48 +273,50 @@ bool FastaReader::next_fastn( SeqRecord &rec )	// FN_fgetseq, dbutil.c:42-128
 	}
 	if( c == EOF )
 		return true;
-	unsigned	cnt = 0;
-	while( ( c = getc( fp_ ) ) != EOF ){
-		if( c == '>' ){
-			ungetc( c, fp_ );
-			break;
-		}
-		if( isalpha( c ) ){
-			cnt++;
-			if( cnt < unsigned( maxslen_ ) ){
-				c = tolower( c );
-				rec.seq.push_back( c == 'u' ? 't' : char( c ) );
-			}
-		}
-	}
-	if( cnt > unsigned( maxslen_ ) )
-		fprintf( stderr, "FN_fgetseq: entry: '%s': seq len: %d, truncated to %d.\n",
-			rec.sid.c_str(), cnt, maxslen_ - 1 );
+	read_letters( "FN_fgetseq", rec );
 	return true;
 }
 
 void PackedDb::add( const char *seq, int n )
 {
+	// letter -> 2-bit code (bits 0-1) and ambiguity flag (bit 2)
+	static unsigned char	lut[ 256 ];
+	static bool	init = false;
+	if( !init ){
+		for( int c = 0; c < 256; c++ )
+			lut[ c ] = 4;
+		lut[ 'a' ] = lut[ 'A' ] = 0;
+		lut[ 'c' ] = lut[ 'C' ] = 1;
+		lut[ 'g' ] = lut[ 'G' ] = 2;
+		lut[ 't' ] = lut[ 'T' ] = lut[ 'u' ] = lut[ 'U' ] = 3;
+		init = true;
+	}
 	base_off.push_back( padded_bases() );
 	slen.push_back( n );
 	total_bases += n;
-	size_t	w2 = codes.size(), w1 = amask.size();
-	size_t	nw1 = ( size_t( n ) + 31 ) / 32;
+	const size_t	w2 = codes.size(), w1 = amask.size();
+	const size_t	nw1 = ( size_t( n ) + 31 ) / 32;
 	codes.resize( w2 + nw1 * 2, 0 );
 	amask.resize( w1 + nw1, 0 );
-	for( int i = 0; i < n; i++ ){
-		unsigned	code;
-		switch( seq[ i ] ){
-		case 'a' : case 'A' : code = 0; break;
-		case 'c' : case 'C' : code = 1; break;
-		case 'g' : case 'G' : code = 2; break;
-		case 't' : case 'T' : case 'u' : case 'U' : code = 3; break;
-		default :
-			code = 0;
-			amask[ w1 + ( i >> 5 ) ] |= 1u << ( i & 31 );
-			break;
+	const unsigned char	*p = reinterpret_cast<const unsigned char *>( seq );
+	uint32_t	*cw = codes.data() + w2, *mw = amask.data() + w1;
+	int	i = 0;
+	for( ; i + 32 <= n; i += 32, p += 32 ){	// one mask word, two code words per step
+		uint32_t	c0 = 0, c1 = 0, m = 0;
+		for( int k = 0; k < 16; k++ ){
+			const unsigned	a = lut[ p[ k ] ], b = lut[ p[ 16 + k ] ];
+			c0 |= ( a & 3u ) << ( 2 * k );
+			c1 |= ( b & 3u ) << ( 2 * k );
+			m |= ( ( a >> 2 ) << k ) | ( ( b >> 2 ) << ( 16 + k ) );
 		}
-		codes[ w2 + ( i >> 4 ) ] |= code << ( 2 * ( i & 15 ) );
+		cw[ i >> 4 ] = c0;
+		cw[ ( i >> 4 ) + 1 ] = c1;
+		mw[ i >> 5 ] = m;
+	}
+	for( ; i < n; i++, p++ ){
+		const unsigned	a = lut[ *p ];
+		cw[ i >> 4 ] |= ( a & 3u ) << ( 2 * ( i & 15 ) );
+		mw[ i >> 5 ] |= ( a >> 2 ) << ( i & 31 );
 	}
 }
 

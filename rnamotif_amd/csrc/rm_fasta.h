@@ -30,9 +30,25 @@ private:
 	bool	next_fastn( SeqRecord &rec );
 	bool	next_pir( SeqRecord &rec );
 	bool	next_gb( SeqRecord &rec );
+	// getc()/ungetc() of the reference's readers over a block buffer (the fastn and pir
+	// readers; the GenBank reader works line by line with fgets on fp_ itself)
+	int	get()
+	{
+		if( pos_ == len_ ){
+			len_ = fread( buf_.data(), 1, buf_.size(), fp_ );
+			pos_ = 0;
+			if( len_ == 0 )
+				return EOF;
+		}
+		return ( unsigned char )buf_[ pos_++ ];
+	}
+	void	unget() { pos_--; }	// only ever the character just read
+	void	read_letters( const char *who, SeqRecord &rec );
 	FILE	*fp_;
 	int	maxslen_;
 	SeqFormat	fmt_;
+	std::vector<char>	buf_ = std::vector<char>( 1 << 20 );
+	size_t	pos_ = 0, len_ = 0;
 };
 
 // Packed database layout (device side):
