@@ -95,3 +95,16 @@ def test_maxslen_and_show_progress(built, workdir, gbrna, tmp_path):
     assert err.count(b"truncated to 100") == sum(1 for r in recs if len(r[2]) > 100)
     prog = [l for l in err.split(b"\n") if b":      " in l and l.rstrip().endswith(tuple(r[0] for r in recs))]
     assert len(prog) == 3 and b"     10: " in prog[0] and prog[0].endswith(recs[9][0])
+
+
+def test_batch_boundaries_do_not_show(built, workdir, gbrna):
+    """The driver hands the scanner batches of entries (RNAMOTIF_BATCH_BASES); stateful score
+    programs (getbest: HOLD/RELEASE across entries) must print the same whatever the batch size."""
+    outs = []
+    for bb in ("1000000000", "3000"):
+        env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"), RNAMOTIF_BATCH_BASES=bb)
+        p = subprocess.run([built["oracle_cli"], "-descr", "getbest.descr", "-N", "2000", gbrna], cwd=workdir, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0, p.stderr.decode()
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] and outs[0].count(b"\n>") > 100
