@@ -91,6 +91,16 @@ struct LdsRecs {
 	__device__ inline void	set( int k, rmd_lrec_t v ) { base[ k * BLOCK ] = v; }
 };
 
+// 64 bits of a bit vector starting at bit q: three dwords through two v_alignbit_b32
+__device__ inline unsigned long long bits64( const unsigned long long *row, int q )
+{
+	const uint32_t	*r = reinterpret_cast<const uint32_t *>( row ) + ( q >> 5 );
+	const uint32_t	d0 = r[ 0 ], d1 = r[ 1 ], d2 = r[ 2 ];
+	const uint32_t	lo = __builtin_amdgcn_alignbit( d1, d0, uint32_t( q & 31 ) );
+	const uint32_t	hi = __builtin_amdgcn_alignbit( d2, d1, uint32_t( q & 31 ) );
+	return ( ( unsigned long long )hi << 32 ) | lo;
+}
+
 // ---------------------------------------------------------------- search kernel
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
@@ -299,10 +309,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						const int	qq = w0 - h - p_lo + 64;
 						unsigned long long	ph = 0;
 						if( qq >= 0 ){
-							const unsigned long long	*row = pb + rmd_code( sq, szero + h ) * pb_words;
-							const int	wi = qq >> 6, sh = qq & 63;
-							const unsigned long long	a0 = row[ wi ], a1 = row[ wi + 1 ];
-							ph = sh ? ( a0 >> sh ) | ( a1 << ( 64 - sh ) ) : a0;
+							ph = bits64( pb + rmd_code( sq, szero + h ) * pb_words, qq );
 						}
 						W &= ph;
 					}
@@ -315,10 +322,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector
 					unsigned long long	ph = 0;
 					if( qq >= 0 ){
-						const unsigned long long	*row = pb + rmd_code( sq, szero + h ) * pb_words;
-						const int	wi = qq >> 6, sh = qq & 63;
-						const unsigned long long	a0 = row[ wi ], a1 = row[ wi + 1 ];
-						ph = sh ? ( a0 >> sh ) | ( a1 << ( 64 - sh ) ) : a0;
+						ph = bits64( pb + rmd_code( sq, szero + h ) * pb_words, qq );
 					}
 					const unsigned long long	mis = ~ph;
 					if( h == 0 )
