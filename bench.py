@@ -85,6 +85,16 @@ def profiled_issue(kernel_ms, kernel="rma_search_kernel"):
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(descr, seqs, budget_bases):
     """The scalar CPU oracle (kind 'port': byte-identical to the reference on
     its golden tests, and within a few percent of its speed here) on a bounded
@@ -100,7 +110,7 @@ def cpu_baseline(descr, seqs, budget_bases):
     t0 = time.perf_counter()
     hits = oracle_scan(descr, sample)
     dt = time.perf_counter() - t0
-    return {"value": round(got / dt / 1e6, 4), "unit": "Mbases/s", "cores": 1, "kind": "port",
+    return {"value": round(got / dt / 1e6, 4), "unit": "Mbases/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
             "sample": f"first {got} bases of the same database, both strands, {hits.shape[0]} candidates, {dt:.1f} s",
             "seconds": round(dt, 2)}
 
@@ -129,7 +139,7 @@ def cpu_baseline_all_cores(descr_path, seqs, bases_per_core):
     wall = time.perf_counter() - t0
     busy = max(r[2] for r in res)
     total = sum(r[0] for r in res)
-    return {"value": round(total / busy / 1e6, 4), "unit": "Mbases/s", "cores": cores, "kind": "port",
+    return {"value": round(total / busy / 1e6, 4), "unit": "Mbases/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": f"{cores} processes x first {bases_per_core} bases of records 0..{cores - 1}, both strands, "
                       f"{sum(r[1] for r in res)} candidates, slowest process {busy:.1f} s (wall {wall:.1f} s with start-up)"}
 
