@@ -1139,6 +1139,7 @@ struct rmd_lean_t {
 	int32_t	szero, slen;
 	int32_t	hi0, lo0;	// first level: end position of rank 0, lowest end position allowed
 	int32_t	rank, order;
+	int32_t	pretested;	// the item is one end position that already passed the first-pairs test
 };
 
 // The interior [a, b] (relative to z) of helix stp ends with a proper helix whose 3' strand
@@ -1187,6 +1188,7 @@ RMD_FN int rmd_lean_begin( const rmd_program_t *P, LR &lr, rmd_lean_t &st, int s
 	const rmd_elem_t	&stp = P->elems[ P->searches[ 0 ] ];
 	st.hi0 = r.sd;
 	st.lo0 = stp.minglen - 1;
+	st.pretested = cnt == 1 && stp.quick;	// (rank items are only made from end positions that passed it)
 	if( r0 > 0 || cnt != RMD_ALL_RANKS ){
 		r.sd = int16_t( st.hi0 - r0 );
 		if( cnt < st.hi0 - st.lo0 + 1 && r.sd - cnt + 1 > st.lo0 )
@@ -1278,7 +1280,7 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 				lo = r.osd - stp.rem_max;
 			if( k == 0 && st.lo0 > lo )
 				lo = st.lo0;
-			if( stp.quick ){
+			if( stp.quick && !( k == 0 && st.pretested ) ){
 				while( r.sd >= lo && !rmd_quick_wchlx( P, stp, sq, z + r.zero, z + r.sd,
 					rmd_s3lim( r.zero, r.sd, stp.q_iminl, stp.maxlen ) + z ) )
 					r.sd--;
