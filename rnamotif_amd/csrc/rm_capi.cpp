@@ -4,6 +4,9 @@
 #include "rnamotif_amd.h"
 #include "rm_cli.h"
 #include "rm_efndata.h"
+#include "rm_pack.h"
+#include <cctype>
+#include <cstddef>
 #include <cstring>
 
 struct rma_descr {
@@ -136,7 +139,6 @@ extern "C" int rma_replay_close( rma_replay_t *rp, char *err, size_t errlen )
 }
 
 // ---------------------------------------------------------------- packed database
-#include "rm_pack.h"
 
 struct rma_pack {
 	rma::PackFile	pf;
