@@ -202,8 +202,26 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		int	p_to = z0 + T + w - 1 + rm;
 		if( p_to > slen )
 			p_to = slen;
-		for( int p = p_from + tid; p < p_to; p += BLOCK )
-			tile[ p - p_lo ] = uint8_t( db_strand_code( db, off, slen, comp, p ) );
+		// one packed word (16 bases) per lane and step; the reverse strand is the same words
+		// read backwards and complemented (mk_rcmp, rnamot.c:193)
+		if( p_from < p_to ){
+			const int	f_lo = comp ? slen - p_to : p_from, f_hi = comp ? slen - 1 - p_from : p_to - 1;
+			const int64_t	w_lo = ( off + f_lo ) >> 4, w_hi = ( off + f_hi ) >> 4;
+			for( int64_t wi = w_lo + tid; wi <= w_hi; wi += BLOCK ){
+				const uint32_t	cw = db.codes[ wi ];
+				const uint32_t	am = db.amask[ wi >> 1 ] >> ( ( wi & 1 ) * 16 );
+				const int	f0 = int( ( wi << 4 ) - off );
+				for( int k = 0; k < 16; k++ ){
+					const int	f = f0 + k;
+					if( f < f_lo || f > f_hi )
+						continue;
+					int	c = ( am >> k ) & 1 ? RMA_BC_N : int( ( cw >> ( 2 * k ) ) & 3 );
+					if( comp && c < 4 )
+						c = 3 - c;
+					tile[ ( comp ? slen - 1 - f : f ) - p_lo ] = uint8_t( c );
+				}
+			}
+		}
 		__syncthreads();
 		// short entries fill only part of a tile: the loops below run over what is there
 		const int	pos_end = rmd_imin( slen - P->dminlen + 1, pos_hi );
