@@ -26,6 +26,9 @@
 #define RMD_COLD	static
 #endif
 
+#ifndef RMD_FN_MEMBER
+#define RMD_FN_MEMBER	inline
+#endif
 #define RMD_UNDEF	(-1)
 
 // host-only instrumentation for tests/hostsim (never defined in the kernel build)
@@ -1249,9 +1252,15 @@ RMD_FN void rmd_lean_emit( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const
 }
 
 // One transition at level k; returns the next level, -1 when the item is done.
-template< class LR, class Sink >
+// A caller may know a faster way to run the tail test of a level (the kernel does, from the
+// bit vectors of its pre-filter): tail( stp, z, a, b, &result ) returns false when it does not.
+struct rmd_no_accel_t {
+	RMD_FN_MEMBER bool	tail( const rmd_elem_t &, int, int, int, bool * ) const { return false; }
+};
+
+template< class LR, class Sink, class Accel = rmd_no_accel_t >
 RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const rmd_seq_t &sq, int k,
-	rmd_lane_t *L, Sink &sink )
+	rmd_lane_t *L, Sink &sink, const Accel &accel = Accel() )
 {
 	const int	d = P->searches[ k ];
 	const rmd_elem_t	&stp = P->elems[ d ];
@@ -1343,8 +1352,13 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 		cand &= cand - 1;
 		if( cur - r.zero - 2 * hl + 1 > stp.maxilen )
 			continue;
-		if( stp.tail_s >= 0 && !rmd_tail_ok( P, stp, sq, z, r.zero + hl, cur - hl ) )
-			continue;
+		if( stp.tail_s >= 0 ){
+			bool	ok;
+			if( !accel.tail( stp, z, r.zero + hl, cur - hl, &ok ) )
+				ok = rmd_tail_ok( P, stp, sq, z, r.zero + hl, cur - hl );
+			if( !ok )
+				continue;
+		}
 		r.hl = uint8_t( hl );
 		r.ph = 1;
 		lr.set( k, r );

@@ -101,6 +101,48 @@ __device__ inline unsigned long long bits64( const unsigned long long *row, int 
 	return ( ( unsigned long long )hi << 32 ) | lo;
 }
 
+// The tail test of rmd_lean_step() from the pre-filter's bit vectors.  pb[c][q] says "the base
+// at q pairs with 5' base c"; when the pair table is symmetric it also says "the base at q,
+// as the 5' partner, pairs with 3' base c".  For a tail helix that allows no mispair and must
+// have both ends paired, "some admissible 5' end s starts it against the 3' end b" is then an
+// AND over its first minlen pairs of windows of those rows -- a few dozen instructions
+// instead of one first-pairs test per admissible s.
+struct TailAccel {
+	const rmd_program_t	*P;
+	const unsigned long long	*pb;
+	const uint8_t	*tile;
+	int	pb_words, p_lo, vec_bits;
+	int	usable_for;		// element index (level-0 helix) the rows were built for, or -1
+	__device__ inline bool	tail( const rmd_elem_t &stp, int z, int a, int b, bool *res ) const
+	{
+		if( usable_for < 0 || stp.searchno != 0 )
+			return false;
+		const rmd_elem_t	&t = P->elems[ P->searches[ stp.tail_s ] ];
+		int	s_hi = b - t.minglen + 1, s_lo = b - t.maxglen + 1;
+		if( a + stp.tail_pre_min > s_lo )
+			s_lo = a + stp.tail_pre_min;
+		if( stp.tail_pre_max >= 0 && a + stp.tail_pre_max < s_hi )
+			s_hi = a + stp.tail_pre_max;
+		const int	n = s_hi - s_lo + 1;
+		if( n <= 0 ){
+			*res = false;
+			return true;
+		}
+		if( n > 64 )
+			return false;
+		unsigned long long	m = n == 64 ? ~0ull : ( 1ull << n ) - 1;
+		for( int j = 0; j < t.minlen && m; j++ ){
+			const int	c3 = tile[ z + b - j - p_lo ];
+			const int	q = z + s_lo + j - p_lo + 64;		// bit of 5' position s_lo + j
+			if( c3 > 4 || q < 0 || q + 64 > vec_bits )
+				return false;
+			m &= bits64( pb + c3 * pb_words, q );
+		}
+		*res = m != 0;
+		return true;
+	}
+};
+
 // ---------------------------------------------------------------- search kernel
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
@@ -475,6 +517,19 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		if constexpr( LEAN ){
 			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
 			rmd_lean_t	st;
+			// the pre-filter's rows serve the tail test of level 0 when the tail helix pairs by
+			// the same (symmetric) table, allows no mispair and has both ends paired
+			TailAccel	accel{ P, pb, tile, pb_words, p_lo, vec_words * 64, -1 };
+			if( bitpar && e0.tail_s >= 0 ){
+				const rmd_elem_t	&te = P->elems[ P->searches[ e0.tail_s ] ];
+				bool	sym = true;
+				for( int x = 0; x < 5; x++ )
+					for( int y = 0; y < 5; y++ )
+						sym = sym && ( ( ( e0_mat2 >> ( x * 5 + y ) ) ^ ( e0_mat2 >> ( y * 5 + x ) ) ) & 1 ) == 0;
+				if( sym && te.pairset == e0.pairset && te.mplim == 0 && !te.pfrac && te.minlen >= 1 &&
+					( te.ends & RMA_5PAIRED ) && ( te.ends & RMA_3PAIRED ) && te.maxglen != RMA_UNBOUNDED )
+					accel.usable_for = 0;
+			}
 			for( ; ; ){
 				const unsigned long long	want = __ballot( k < 0 && !dry );
 				if( want ){
@@ -496,7 +551,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( __ballot( k >= 0 ) == 0 )
 					break;
 				if( k >= 0 )
-					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink );
+					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink, accel );
 			}
 		}else
 		for( ; ; ){
