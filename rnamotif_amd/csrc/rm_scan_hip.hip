@@ -531,8 +531,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					accel.usable_for = 0;
 			}
 			for( ; ; ){
-				const unsigned long long	want = __ballot( k < 0 && !dry );
-				if( want ){
+				// lanes without work pop until they hold an item that survives the tail test
+				for( unsigned long long want; ( want = __ballot( k < 0 && !dry ) ) != 0; ){
 					int	base = 0;
 					if( lane_id == __ffsll( want ) - 1 )
 						base = atomicAdd( &s_qhead, __popcll( want ) );
@@ -542,8 +542,27 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						if( i < nq ){
 							const unsigned	item = queue[ i ];
 							const int	r = int( item & 0xffffu );
-							k = rmd_lean_begin( P, lr, st, z0 + int( item >> 16 ), slen,
-								r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+							const int	szero = z0 + int( item >> 16 );
+							bool	drop = false;
+							if( accel.usable_for >= 0 && r != 0xffff ){
+								// the tail test for every helix length the end position allows,
+								// before any search state is set up: nine items in ten end here
+								int	hi, lo;
+								rmd_level0_range( P, szero, slen, &hi, &lo );
+								const int	span = hi - r - szero + 1;
+								drop = true;
+								for( int hl = e0.minlen; hl <= e0.maxlen && drop; hl++ ){
+									const int	ilen = span - 2 * hl;
+									if( ilen < e0.minilen )
+										break;
+									bool	ok;
+									if( ilen <= e0.maxilen && ( !accel.tail( e0, szero, hl, span - 1 - hl, &ok ) || ok ) )
+										drop = false;
+								}
+							}
+							if( !drop )
+								k = rmd_lean_begin( P, lr, st, szero, slen,
+									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
 						}else
 							dry = true;
 					}
