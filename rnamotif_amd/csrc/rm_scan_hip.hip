@@ -795,9 +795,10 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		// The search of a tile ends with a few long-running items on a few lanes, so fewer,
 		// larger tiles are better as long as four workgroups still share a CU's 160 KB of
 		// LDS (measured on trna.descr, ms per 100 Mbase: T = 2048 6.97, 4096 5.87, 6144 5.40,
-		// and 6.9 again at 8192 where only three fit).
-		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 256;
-		for( int t = 8192; t >= 2048; t -= 512 )
+		// 6656 4.39 with the
+		// later kernel, and 5.4 at 7168 where only three fit).
+		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64;	// (static __shared__: 32 bytes)
+		for( int t = 8192; t >= 2048; t -= 256 )
 			if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true, sc->qcap ) <= budget ){
 				sc->tile_t = t;
 				break;
