@@ -21,6 +21,7 @@
 #include <cstring>
 #include <numeric>
 #include <chrono>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -83,12 +84,33 @@ struct DevSink {
 #define QCAP		1024		// work queue entries per workgroup
 #endif
 
-// lean path records of one lane: level k at base[ k * BLOCK ] (lane-contiguous 8-byte slots)
+// Lean path records of one lane in LDS, 6 bytes per level: windows of lean descriptors are
+// shorter than 4096 (rmd_build), so window start and saved end take 12 bits each, the next
+// end position (which may be one below the start: -1) 13, the helix length 6, the phase 1.
+// Level k: a dword at lo[ k * BLOCK ] and a half word at hi[ k * BLOCK ], lane-contiguous.
+#define LEAN_REC_BYTES	6
 template< int BLOCK >
 struct LdsRecs {
-	rmd_lrec_t	*base;
-	__device__ inline rmd_lrec_t	get( int k ) const { return base[ k * BLOCK ]; }
-	__device__ inline void	set( int k, rmd_lrec_t v ) { base[ k * BLOCK ] = v; }
+	uint32_t	*lo;
+	uint16_t	*hi;
+	__device__ inline rmd_lrec_t	get( int k ) const
+	{
+		const uint32_t	a = lo[ k * BLOCK ];
+		const uint32_t	b = hi[ k * BLOCK ];
+		rmd_lrec_t	r;
+		r.zero = int16_t( a & 0xfffu );
+		r.osd = int16_t( ( a >> 12 ) & 0xfffu );
+		r.sd = int16_t( int( ( a >> 24 ) | ( ( b & 0x1fu ) << 8 ) ) - 1 );
+		r.hl = uint8_t( ( b >> 5 ) & 0x3fu );
+		r.ph = uint8_t( b >> 11 );
+		return r;
+	}
+	__device__ inline void	set( int k, rmd_lrec_t v )
+	{
+		const uint32_t	sd1 = uint32_t( int( v.sd ) + 1 );
+		lo[ k * BLOCK ] = uint32_t( v.zero ) | ( uint32_t( v.osd ) << 12 ) | ( sd1 << 24 );
+		hi[ k * BLOCK ] = uint16_t( ( ( sd1 >> 8 ) & 0x1fu ) | ( uint32_t( v.hl ) << 5 ) | ( uint32_t( v.ph ) << 11 ) );
+	}
 };
 
 // 64 bits of a bit vector starting at bit q: three dwords through two v_alignbit_b32
@@ -196,8 +218,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + prog_bytes + qcap * sizeof( unsigned ) +
 		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
 	unsigned long long	*occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
-	rmd_lrec_t	*lean = reinterpret_cast<rmd_lrec_t *>( occ + pb_words );
-	LdsRecs<BLOCK>	lr{ lean + threadIdx.x };
+	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( occ + pb_words );
+	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
+	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
 	const int	lit_n = lit ? rmd_regexes( P )[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
@@ -731,7 +754,7 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 	const size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
 	if( lean )
-		lds += size_t( dp.n_searches ) * 256 * sizeof( rmd_lrec_t );
+		lds += size_t( dp.n_searches ) * 256 * LEAN_REC_BYTES;
 	return lds;
 }
 
@@ -793,16 +816,40 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	sc->grid_blocks = prop.multiProcessorCount * 8;
 	if( sc->dprog.lean_ok ){
 		// The search of a tile ends with a few long-running items on a few lanes, so fewer,
-		// larger tiles are better as long as four workgroups still share a CU's 160 KB of
-		// LDS (measured on trna.descr, ms per 100 Mbase: T = 2048 6.97, 4096 5.87, 6144 5.40,
-		// 6656 4.39 with the
-		// later kernel, and 5.4 at 7168 where only three fit).
+		// larger tiles are better as long as four workgroups still share a CU's 160 KB of LDS
+		// (trna.descr, ms per 100 Mbase: T = 2048 6.97, 4096 5.87, 6144 5.40 with 8-byte records;
+		// 6656 4.38, 9984 3.99 with 6-byte records; one step further only three fit: 5.0) and the
+		// work queue still holds what the pre-filter lets through: on random sequence a start
+		// position yields n_rank * P( first minlen pairs hold, at most lim mispairs ) items.
+		const rmd_program_t	&dp = sc->dprog;
+		const rmd_elem_t	&e0 = dp.elems[ dp.searches[ 0 ] ];
+		double	density = 1.0;
+		if( e0.type == RMA_T_H5 && e0.pairset >= 0 && e0.minlen >= 1 ){
+			const uint32_t	m2 = rmd_pairsets( &dp )[ e0.pairset ].mat2;
+			int	np = 0;
+			for( int a = 0; a < 4; a++ )
+				for( int b = 0; b < 4; b++ )
+					np += ( m2 >> ( a * 5 + b ) ) & 1;
+			const double	pp = np / 16.0;
+			const int	lim = ( e0.ends & RMA_5PAIRED ) ? e0.mplim : std::max( e0.mplim, 1 );
+			double	p = 0, comb = 1;
+			for( int m = 0; m <= lim && m <= e0.minlen; m++ ){
+				p += comb * std::pow( pp, e0.minlen - m ) * std::pow( 1 - pp, m );
+				comb = comb * ( e0.minlen - m ) / ( m + 1 );
+			}
+			const int	w = dp.w_winsize;
+			const int	n_rank = ( e0.maxglen != RMA_UNBOUNDED && e0.maxglen < w ? e0.maxglen : w ) - e0.minglen + 1;
+			density = std::min( 1.0, p ) * std::max( 1, n_rank );
+		}
 		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64;	// (static __shared__: 32 bytes)
-		for( int t = 8192; t >= 2048; t -= 256 )
-			if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true, sc->qcap ) <= budget ){
+		sc->tile_t = 2048;
+		for( int t = 16384; t >= 2048; t -= 256 )
+			if( search_lds_bytes( sc->prog_bytes, dp, t, true, sc->qcap ) <= budget && density * t * 1.1 <= sc->qcap ){
 				sc->tile_t = t;
 				break;
 			}
+		if( density * sc->tile_t * 1.1 > sc->qcap )	// dense survivors: a longer queue rather than the in-place fallback
+			sc->qcap = int( std::min( 8192.0, std::ceil( density * sc->tile_t * 1.2 / 256 ) * 256 ) );
 	}
 	if( !sc->dprog.lean_ok ){
 		// general instance: LDS is not what limits it (frames live in scratch), so larger
