@@ -841,6 +841,18 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 			const int	n_rank = ( e0.maxglen != RMA_UNBOUNDED && e0.maxglen < w ? e0.maxglen : w ) - e0.minglen + 1;
 			density = std::min( 1.0, p ) * std::max( 1, n_rank );
 		}
+		if( dp.lit_re >= 0 ){
+			// ... and only where the best literal occurs at an allowed offset
+			const rmd_regex_t	&lre = rmd_regexes( &dp )[ dp.lit_re ];
+			double	pl = 1.0;
+			for( int j = 0; j < lre.n_states; j++ ){
+				int	n = 0;
+				for( int c = 0; c < 4; c++ )
+					n += int( ( lre.accept[ c ] >> j ) & 1 );
+				pl *= n / 4.0;
+			}
+			density *= std::min( 1.0, pl * ( dp.lit_hi - dp.lit_lo + 1 ) );
+		}
 		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64;	// (static __shared__: 32 bytes)
 		sc->tile_t = 2048;
 		for( int t = 16384; t >= 2048; t -= 256 )
