@@ -200,13 +200,15 @@ def main():
         """Variable length gather of hit records to rank 0 over RCCL (rnamotif_amd/distributed.py,
         the same function the world-size-2 gloo test runs)."""
         if world == 1:
-            return h
-        return gather_to_rank0(h, my_index, stride, device=dev)
+            return [h]
+        # every rank holds a consecutive run of entries: the per-rank arrays in rank order are the
+        # ordered hit stream of the whole job, left as they arrive (no concatenation on rank 0)
+        return gather_to_rank0(h, my_index, stride, device=dev, concat=False)
 
     def step():
         n = 0
         for d_, sc_, db_ in zip(descrs, scs, dbs):
-            n += gather_hits(sc_.scan(db_), d_.hit_stride).shape[0]
+            n += sum(part.shape[0] for part in gather_hits(sc_.scan(db_), d_.hit_stride))
         return n
 
     for _ in range(args.warmup):

@@ -60,13 +60,17 @@ def partition_ranges(lengths: Sequence[int], world: int, max_chunk: int = 0) -> 
     return parts
 
 
-def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int, device=None) -> np.ndarray:
+def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int, device=None,
+                concat: bool = True):
     """Gather int32 hit records [n, stride] from every rank to rank 0.
 
     `global_index[i]` is the database-wide index of the rank's i-th sequence;
     word 0 of every record is rewritten to it before sending.  Rank 0 returns all
     records sorted by (seq, comp, szero, rank, order) -- the reference's output
-    order over the whole database; other ranks return an empty array.
+    order over the whole database; other ranks return an empty array.  With
+    concat=False rank 0 gets the per-rank arrays (each in order, in rank order) as a
+    list instead: when the ranks hold consecutive runs of entries that list *is* the
+    ordered hit stream and a consumer can walk it without the copy.
     """
     import torch
     import torch.distributed as dist
@@ -92,11 +96,13 @@ def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int
         for q in reqs:
             q.wait()
         parts = [h] + [bufs[r].cpu().numpy() for r in sorted(bufs)]
+        if not concat:
+            return parts
         allh = np.concatenate(parts, axis=0) if len(parts) > 1 else h
         return sort_hits(allh)
     if h.shape[0]:
         dist.send(torch.from_numpy(h).to(dev), dst=0)
-    return np.zeros((0, stride), dtype=np.int32)
+    return np.zeros((0, stride), dtype=np.int32) if concat else []
 
 
 def sort_hits(allh: np.ndarray) -> np.ndarray:
