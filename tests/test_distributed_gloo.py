@@ -29,10 +29,10 @@ parts = partition_by_bases([len(s) for s in seqs], world)
 mine = parts[rank]
 local = oracle_scan(d, [seqs[i] for i in mine])
 allh = gather_hits(local, mine, d.hit_stride)
-parts = gather_hits(local, mine, d.hit_stride, concat=False)      # the form bench.py takes
+hparts = gather_hits(local, mine, d.hit_stride, concat=False)     # the form bench.py takes
 if rank == 0:
     from rnamotif_amd.distributed import sort_hits
-    assert len(parts) == world and np.array_equal(sort_hits(np.concatenate(parts, axis=0)), allh)
+    assert len(hparts) == world and np.array_equal(sort_hits(np.concatenate(hparts, axis=0)), allh)
     want = oracle_scan(d, seqs)
     assert sorted(sum(parts, [])) == list(range(len(seqs)))
     assert allh.shape == want.shape and np.array_equal(allh, want), (allh.shape, want.shape)
