@@ -208,7 +208,7 @@ def main():
     def step():
         n = 0
         for d_, sc_, db_ in zip(descrs, scs, dbs):
-            n += sum(part.shape[0] for part in gather_hits(sc_.scan(db_), d_.hit_stride))
+            n += sum(part.shape[0] for part in gather_hits(sc_.scan(db_, copy=False), d_.hit_stride))
         return n
 
     for _ in range(args.warmup):

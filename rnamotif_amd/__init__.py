@@ -212,8 +212,9 @@ class Scanner:
     def database_from_pack(self, pack: "Pack", first: int = 0, count: Optional[int] = None) -> Database:
         return Database(self, pack=pack, first=first, count=count)
 
-    def scan(self, db: Database) -> np.ndarray:
-        """All candidates of db in reference order: int32 array [n, hit_stride]."""
+    def scan(self, db: Database, copy: bool = True) -> np.ndarray:
+        """All candidates of db in reference order: int32 array [n, hit_stride].  With
+        copy=False the array is a view of the scanner's own buffer, valid until its next scan."""
         L = lib()
         hits = C.POINTER(C.c_int32)()
         n = C.c_int64()
@@ -223,7 +224,8 @@ class Scanner:
         if n.value == 0:
             return np.zeros((0, stride), dtype=np.int32)
         a = np.ctypeslib.as_array(hits, shape=(n.value * stride,))
-        return a.reshape(n.value, stride).copy()
+        a = a.reshape(n.value, stride)
+        return a.copy() if copy else a
 
     def scan_device(self, db: Database) -> Tuple[int, float, float]:
         """Device part only: (candidates, search kernel ms, efn kernel ms)."""
