@@ -1174,7 +1174,9 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 		keys[ i ].b = ( uint64_t( uint32_t( x[ 3 ] ) ) << 32 ) | uint32_t( x[ 4 ] );
 		keys[ i ].i = i;
 	}
+	lap( "keys" );
 	std::sort( keys.begin(), keys.end(), []( const Key &x, const Key &y ){ return x.a != y.a ? x.a < y.a : x.b < y.b; } );
+	lap( "sort" );
 	sc->h_sorted.resize( words );
 	for( int64_t i = 0; i < n; i++ )
 		memcpy( &sc->h_sorted[ size_t( i ) * stride ], d + keys[ i ].i * stride, stride * sizeof( int32_t ) );
