@@ -1058,6 +1058,10 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	*n_hits = 0;
 	if( search_ms ) *search_ms = 0;
 	if( efn_ms ) *efn_ms = 0;
+	if( db->sc != sc ){
+		snprintf( err, errlen, "the database was created for another scanner (tiles are laid out per scanner)" );
+		return 1;
+	}
 	if( sc->need_efn2 && sc->d_efn2 == nullptr ){
 		snprintf( err, errlen, "the program has efn2() call sites but rma_scanner_set_efn2data() was not called" );
 		return 1;
