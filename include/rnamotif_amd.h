@@ -64,7 +64,8 @@ void	rma_scanner_destroy( rma_scanner_t *sc );
 
 /* ---- database: n sequences of lower case letters as the reference's readers
  * deliver them (dbutil.c: every alpha character kept, u -> t).  They are packed
- * 2 bits + 1 ambiguity bit per base and uploaded; the host text is not kept. */
+ * 2 bits + 1 ambiguity bit per base and uploaded; the host text is not kept.  A database
+ * belongs to the scanner it was created for (its tiles are laid out for that descriptor). */
 int	rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
 		rma_db_t **out, char *err, size_t errlen );
 /* The same, answering only for start positions pos_lo[i] <= szero < pos_hi[i] of each strand
