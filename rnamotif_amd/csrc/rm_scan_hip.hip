@@ -86,7 +86,7 @@ struct DevSink {
 
 // Lean path records of one lane in LDS, 6 bytes per level: windows of lean descriptors are
 // shorter than 4096 (rmd_build), so window start and saved end take 12 bits each, the next
-// end position (which may be one below the start: -1) 13, the helix length 6, the phase 1.
+// end position (down to -2) 13, the helix length 6, the phase 1.
 // Level k: a dword at lo[ k * BLOCK ] and a half word at hi[ k * BLOCK ], lane-contiguous.
 #define LEAN_REC_BYTES	6
 template< int BLOCK >
@@ -99,16 +99,18 @@ struct LdsRecs {
 		const uint32_t	b = hi[ k * BLOCK ];
 		rmd_lrec_t	r;
 		r.zero = int16_t( a & 0xfffu );
-		r.osd = int16_t( ( a >> 12 ) & 0xfffu );
-		r.sd = int16_t( int( ( a >> 24 ) | ( ( b & 0x1fu ) << 8 ) ) - 1 );
+		r.osd = int16_t( int( ( a >> 12 ) & 0xfffu ) - 1 );
+		r.sd = int16_t( int( ( a >> 24 ) | ( ( b & 0x1fu ) << 8 ) ) - 2 );
 		r.hl = uint8_t( ( b >> 5 ) & 0x3fu );
 		r.ph = uint8_t( b >> 11 );
 		return r;
 	}
 	__device__ inline void	set( int k, rmd_lrec_t v )
 	{
-		const uint32_t	sd1 = uint32_t( int( v.sd ) + 1 );
-		lo[ k * BLOCK ] = uint32_t( v.zero ) | ( uint32_t( v.osd ) << 12 ) | ( sd1 << 24 );
+		// saved end >= -1 (empty interior at the window start), next end >= -2 (one below an
+		// element that may be empty at position 0): stored with offsets 1 and 2
+		const uint32_t	sd1 = uint32_t( int( v.sd ) + 2 ) & 0x1fffu;
+		lo[ k * BLOCK ] = ( uint32_t( v.zero ) & 0xfffu ) | ( ( uint32_t( int( v.osd ) + 1 ) & 0xfffu ) << 12 ) | ( sd1 << 24 );
 		hi[ k * BLOCK ] = uint16_t( ( ( sd1 >> 8 ) & 0x1fu ) | ( uint32_t( v.hl ) << 5 ) | ( uint32_t( v.ph ) << 11 ) );
 	}
 };

@@ -372,3 +372,108 @@ def test_one_long_entry(built, workdir):
     ln = whole[:, 6::4][:, :d.n_elems]
     assert np.all(off[:, 1:] == off[:, :-1] + ln[:, :-1]) and np.all(off[:, 0] == whole[:, 2])
     assert whole[:, 2].max() > 11_000_000 and np.all(off[:, -1] + ln[:, -1] <= len(seq))
+
+
+def _random_descriptor(rng):
+    """A random nested descriptor of ss and Watson-Crick helices (the lean path's domain) with
+    random lengths, mispair / pairfrac / ends settings, pair sets and seq= constraints."""
+    lines = []
+
+    def ss(indent, force=False):
+        r = rng.random()
+        if r < 0.3:
+            n = int(rng.integers(1, 7))
+            spec = "len=%d" % n
+            if rng.random() < 0.3:
+                k = int(rng.integers(0, n))
+                spec += ', seq="^%s%s"' % ("." * k, "acgt"[int(rng.integers(0, 4))])
+        else:
+            lo = int(rng.integers(0 if not force else 1, 5))
+            hi = lo + int(rng.integers(0, 9))
+            if hi == 0:
+                hi = 1
+            spec = "minlen=%d,maxlen=%d" % (lo, hi)
+            if rng.random() < 0.15:
+                spec += ', seq="%s"' % "".join("acgtn"[int(x)] for x in rng.integers(0, 5, size=int(rng.integers(1, 3))))
+        lines.append("\t" * indent + "ss(%s)" % spec)
+
+    def helix(indent, depth):
+        lo = int(rng.integers(2, 6))
+        hi = lo + int(rng.integers(0, 4))
+        spec = "minlen=%d,maxlen=%d" % (lo, hi)
+        r = rng.random()
+        if r < 0.25:
+            spec += ",mispair=%d" % int(rng.integers(1, 3))
+        elif r < 0.35:
+            spec += ",pairfrac=%.2f" % (0.6 + 0.35 * rng.random())
+        if rng.random() < 0.25:
+            spec += ",ends='%s'" % ["mm", "pm", "mp", "pp"][int(rng.integers(0, 4))]
+        if rng.random() < 0.15:
+            spec += ',pair+=gu'
+        if rng.random() < 0.1:
+            spec += ',seq="^%s"' % "acgt"[int(rng.integers(0, 4))]
+        lines.append("\t" * indent + "h5(%s)" % spec)
+        interior(indent + 1, depth + 1)
+        lines.append("\t" * indent + "h3")
+
+    def interior(indent, depth):
+        n_hlx = 0 if depth >= 3 else int(rng.choice([0, 1, 1, 2, 3] if depth < 2 else [0, 0, 1]))
+        if n_hlx == 0:
+            ss(indent, force=True)
+            return
+        if rng.random() < 0.7:
+            ss(indent)
+        for k in range(n_hlx):
+            helix(indent, depth)
+            if k < n_hlx - 1 or rng.random() < 0.7:
+                ss(indent)
+
+    if rng.random() < 0.3:
+        ss(1)
+    helix(1, 0)
+    if rng.random() < 0.5:
+        ss(1)
+    parms = "parms\n\twc += gu;\n" if rng.random() < 0.5 else ""
+    return parms + "descr\n" + "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_descriptors_equal_oracle(built, tmp_path, seed):
+    """Differential test over generated descriptors: every pruning rule, tile choice and queue
+    path of the lean instance (and the general one where the generator's ss(minlen=0) or windows
+    push a descriptor there) against the oracle, records bit for bit."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(1000 + seed)
+    text = _random_descriptor(rng)
+    path = tmp_path / "rand.descr"
+    path.write_text(text)
+    try:
+        d = R.Descriptor(["-descr", str(path)])
+    except R.RnamotifError:
+        pytest.skip("generated descriptor does not compile (length constraints)")
+    if d.maxlen > 600:
+        pytest.skip("window too large for a quick differential run")
+    try:
+        sc = R.Scanner(d)
+    except R.RnamotifError as e:
+        pytest.skip("refused by the device build: " + str(e))
+    lut = np.frombuffer(b"acgtn", dtype=np.uint8)
+    # biased composition and planted inverted repeats so that helices actually form
+    n = 12_000
+    v = rng.choice(5, size=n, p=[0.2, 0.3, 0.3, 0.19, 0.01])
+    s = bytearray(lut[v].tobytes())
+    comp = {ord("a"): ord("t"), ord("c"): ord("g"), ord("g"): ord("c"), ord("t"): ord("a"), ord("n"): ord("n")}
+    for _ in range(150):
+        a = int(rng.integers(0, n - 80))
+        k = int(rng.integers(4, 10))
+        gap = int(rng.integers(3, 50))
+        if a + 2 * k + gap < n:
+            s[a + k + gap:a + 2 * k + gap] = bytes(comp[c] for c in reversed(s[a:a + k]))
+    seqs = [bytes(s), bytes(s[:257])]
+    want = oracle_scan(d, seqs)
+    if want.shape[0] > 400_000:
+        pytest.skip("too many candidates for a quick run")
+    got = sc.scan(sc.database(seqs))
+    assert got.shape == want.shape, text
+    assert np.array_equal(got, want), text
