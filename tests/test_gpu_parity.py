@@ -437,7 +437,7 @@ def _random_descriptor(rng):
     return parms + "descr\n" + "\n".join(lines) + "\n"
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(160))
 def test_random_descriptors_equal_oracle(built, tmp_path, seed):
     """Differential test over generated descriptors: every pruning rule, tile choice and queue
     path of the lean instance (and the general one where the generator's ss(minlen=0) or windows
@@ -473,6 +473,138 @@ def test_random_descriptors_equal_oracle(built, tmp_path, seed):
     seqs = [bytes(s), bytes(s[:257])]
     want = oracle_scan(d, seqs)
     if want.shape[0] > 400_000:
+        pytest.skip("too many candidates for a quick run")
+    got = sc.scan(sc.database(seqs))
+    assert got.shape == want.shape, text
+    assert np.array_equal(got, want), text
+
+
+def _random_general_descriptor(rng):
+    """Random descriptors for the general instance: pseudoknots, parallel helices, triplexes,
+    4-plexes and hairpins side by side, with mispairs, mismatches, ends and sites."""
+    lines, sites = [], []
+    tag = [0]
+
+    def ss(indent, lo=0, hi=6):
+        a = int(rng.integers(lo, hi))
+        b = a + int(rng.integers(0, 5))
+        if b == 0:
+            b = 1
+        spec = "minlen=%d,maxlen=%d" % (a, b)
+        if rng.random() < 0.2:
+            spec = "len=%d" % max(1, b)
+        if rng.random() < 0.15:
+            spec += ', seq="%s"' % "".join("acgt"[int(x)] for x in rng.integers(0, 4, size=2))
+            if rng.random() < 0.3:
+                spec += ",mismatch=1"
+        lines.append("\t" * indent + "ss(%s)" % spec)
+
+    def hspec(lo_min=2):
+        lo = int(rng.integers(lo_min, 5))
+        hi = lo + int(rng.integers(0, 3))
+        spec = "minlen=%d,maxlen=%d" % (lo, hi)
+        r = rng.random()
+        if r < 0.3:
+            spec += ",mispair=1"
+        elif r < 0.4:
+            spec += ",pairfrac=%.2f" % (0.6 + 0.3 * rng.random())
+        if rng.random() < 0.2:
+            spec += ",ends='%s'" % ["mm", "pm", "mp", "pp"][int(rng.integers(0, 4))]
+        return spec
+
+    def hairpin(indent):
+        lines.append("\t" * indent + "h5(%s)" % hspec())
+        ss(indent + 1, 3, 6)
+        lines.append("\t" * indent + "h3")
+
+    def pknot(indent):
+        tag[0] += 2
+        a, b = tag[0] - 1, tag[0]
+        lines.append("\t" * indent + "h5(tag='%d',%s)" % (a, hspec()))
+        ss(indent + 1)
+        lines.append("\t" * indent + "h5(tag='%d',%s)" % (b, hspec()))
+        ss(indent + 1, 1, 4)
+        lines.append("\t" * indent + "h3(tag='%d')" % a)
+        ss(indent + 1)
+        lines.append("\t" * indent + "h3(tag='%d')" % b)
+        if rng.random() < 0.4:
+            sites.append("h5(tag='%d',pos=1):h3(tag='%d',pos=$) in { 'g:c', 'c:g', 'a:t', 't:a' }" % (a, a))
+
+    def phlx(indent):
+        lines.append("\t" * indent + "p5(%s)" % hspec())
+        ss(indent + 1, 2, 6)
+        lines.append("\t" * indent + "p3")
+
+    def triplex(indent):
+        tag[0] += 1
+        lines.append("\t" * indent + "t1(tag='%d',%s)" % (tag[0], hspec(3)))
+        ss(indent + 1, 3, 6)
+        lines.append("\t" * indent + "t2(tag='%d')" % tag[0])
+        ss(indent + 1, 3, 6)
+        lines.append("\t" * indent + "t3(tag='%d')" % tag[0])
+
+    def quad(indent):
+        tag[0] += 1
+        lines.append("\t" * indent + "q1(tag='%d',minlen=2,maxlen=3%s)" % (tag[0], ",mispair=1" if rng.random() < 0.5 else ""))
+        for k in (2, 3, 4):
+            ss(indent + 1, 2, 5)
+            lines.append("\t" * indent + "q%d(tag='%d')" % (k, tag[0]))
+
+    units = [hairpin, pknot, pknot, phlx, triplex, quad]
+    if rng.random() < 0.4:
+        ss(1, 1, 4)
+    for k in range(int(rng.integers(1, 3))):
+        units[int(rng.integers(0, len(units)))](1)
+        if rng.random() < 0.6:
+            ss(1, 0, 4)
+    text = ("parms\n\twc += gu;\n" if rng.random() < 0.5 else "") + "descr\n" + "\n".join(lines) + "\n"
+    if sites:
+        text += "sites\n\t" + "\n\t".join(sites) + "\n"
+    return text
+
+
+def _planted_sequence(rng, n):
+    lut = np.frombuffer(b"acgtn", dtype=np.uint8)
+    v = rng.choice(5, size=n, p=[0.2, 0.3, 0.3, 0.19, 0.01])
+    s = bytearray(lut[v].tobytes())
+    comp = {ord("a"): ord("t"), ord("c"): ord("g"), ord("g"): ord("c"), ord("t"): ord("a"), ord("n"): ord("n")}
+    for _ in range(n // 80):
+        a = int(rng.integers(0, n - 80))
+        k = int(rng.integers(4, 10))
+        gap = int(rng.integers(3, 50))
+        if a + 2 * k + gap < n:
+            s[a + k + gap:a + 2 * k + gap] = bytes(comp[c] for c in reversed(s[a:a + k]))
+    for _ in range(n // 60):            # runs of g for the 4-plexes, of a / t for the triplexes
+        a = int(rng.integers(0, n - 12))
+        k = int(rng.integers(3, 9))
+        s[a:a + k] = bytes([ord("ggat"[int(rng.integers(0, 4))])]) * k
+    return bytes(s)
+
+
+@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("seed", range(40))
+def test_random_general_descriptors_equal_oracle(built, tmp_path, seed, strict):
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(5000 + seed)
+    text = _random_general_descriptor(rng)
+    path = tmp_path / "rand.descr"
+    path.write_text(text)
+    argv = (["-sh", "-context", "-Dctx_maxlen=4"] if strict else []) + ["-descr", str(path)]
+    try:
+        d = R.Descriptor(argv)
+    except R.RnamotifError:
+        pytest.skip("generated descriptor does not compile")
+    if d.maxlen > 160:
+        pytest.skip("window too large for a quick differential run")
+    try:
+        sc = R.Scanner(d)
+    except R.RnamotifError as e:
+        pytest.skip("refused by the device build: " + str(e))
+    s = _planted_sequence(rng, 6_000)
+    seqs = [s, s[:301]]
+    want = oracle_scan(d, seqs)
+    if want.shape[0] > 300_000:
         pytest.skip("too many candidates for a quick run")
     got = sc.scan(sc.database(seqs))
     assert got.shape == want.shape, text
