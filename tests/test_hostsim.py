@@ -50,3 +50,31 @@ def test_efn2_device_core_equals_oracle(hostsim, workdir):
                        stderr=subprocess.PIPE, timeout=1800)
     assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
     assert b"1351 candidates, 0 mismatching strands (1351 efn2 energies compared)" in p.stdout
+
+
+def test_generated_descriptors(hostsim, tmp_path):
+    """The generators of tests/test_gpu_parity.py on the CPU: the device state machine (lean and
+    general paths), compiled for the host, against the oracle on 30 + 30 generated descriptors."""
+    import numpy as np
+    import rnamotif_amd as R
+    import test_gpu_parity as T
+    ran = 0
+    for kind, gen, base, n in (("lean", T._random_descriptor, 1000, 30), ("general", T._random_general_descriptor, 5000, 30)):
+        for seed in range(n):
+            rng = np.random.default_rng(base + seed)
+            path = tmp_path / ("%s_%d.descr" % (kind, seed))
+            path.write_text(gen(rng))
+            try:
+                d = R.Descriptor(["-descr", str(path)])
+            except R.RnamotifError:
+                continue
+            if d.maxlen > 160:
+                continue
+            s = T._planted_sequence(rng, 4_000)
+            fa = tmp_path / "db.fastn"
+            fa.write_bytes(b">a x\n" + s + b"\n>b y\n" + s[:301] + b"\n")
+            p = subprocess.run([hostsim, "-descr", str(path), str(fa)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=120)
+            assert p.returncode == 0 and b" 0 mismatching strands" in p.stdout, (kind, seed, p.stdout[-300:], p.stderr[-300:])
+            ran += 1
+    assert ran >= 40
