@@ -609,3 +609,45 @@ def test_random_general_descriptors_equal_oracle(built, tmp_path, seed, strict):
     got = sc.scan(sc.database(seqs))
     assert got.shape == want.shape, text
     assert np.array_equal(got, want), text
+
+
+@pytest.mark.parametrize("gen", ["lean", "general"])
+@pytest.mark.parametrize("seed", range(40))
+def test_random_descriptors_under_stress_settings(built, tmp_path, seed, gen):
+    """The same generated descriptors with tiles of 256 positions and a work queue of 64 entries:
+    almost every tile overflows its queue, so the in-place search of the pre-filter, the tile
+    edges and the ragged last tiles carry the load.  Entries of awkward lengths ride along."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng((1000 if gen == "lean" else 5000) + seed)
+    text = _random_descriptor(rng) if gen == "lean" else _random_general_descriptor(rng)
+    path = tmp_path / "rand.descr"
+    path.write_text(text)
+    try:
+        d = R.Descriptor(["-descr", str(path)])
+    except R.RnamotifError:
+        pytest.skip("generated descriptor does not compile")
+    if d.maxlen > 160:
+        pytest.skip("window too large for a quick differential run")
+    s = _planted_sequence(rng, 5_000)
+    seqs = [s, b"", s[:max(d.minlen - 1, 0)], s[:d.minlen], s[:d.maxlen], s[:d.maxlen + 1], s[100:100 + 255], s[7:7 + 513]]
+    want = oracle_scan(d, seqs)
+    if want.shape[0] > 300_000:
+        pytest.skip("too many candidates for a quick run")
+    old = {k: os.environ.get(k) for k in ("RNAMOTIF_TILE", "RNAMOTIF_QCAP")}
+    os.environ["RNAMOTIF_TILE"] = "256"
+    os.environ["RNAMOTIF_QCAP"] = "64"
+    try:
+        try:
+            sc = R.Scanner(d)
+        except R.RnamotifError as e:
+            pytest.skip("refused by the device build: " + str(e))
+        got = sc.scan(sc.database(seqs))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert got.shape == want.shape, text
+    assert np.array_equal(got, want), text
