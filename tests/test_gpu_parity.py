@@ -651,3 +651,35 @@ def test_random_descriptors_under_stress_settings(built, tmp_path, seed, gen):
                 os.environ[k] = v
     assert got.shape == want.shape, text
     assert np.array_equal(got, want), text
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_descriptors_with_energy_sites(built, tmp_path, seed):
+    """Generated nested descriptors scored with efn() and efn2() over their outermost helix:
+    both energies of every candidate (hairpins, bulges, interior and multi-branch loops as the
+    generator nests them) equal the oracle's."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(1000 + seed)
+    text = _random_descriptor(rng)
+    elems = [l for l in text.split("descr\n")[1].split("\n") if l.strip()]
+    tops = [i + 1 for i, l in enumerate(elems) if l.startswith("\th") and not l.startswith("\t\t")]
+    a, b = tops[0], tops[-1]
+    text += "score\n\t{ SCORE = sprintf( '%%8.3f %%8.3f', efn( h5[%d], h3[%d] ), efn2( h5[%d], h3[%d] ) ); }\n" % (a, b, a, b)
+    path = tmp_path / "rand.descr"
+    path.write_text(text)
+    try:
+        d = R.Descriptor(["-descr", str(path)])
+    except R.RnamotifError:
+        pytest.skip("generated descriptor does not compile")
+    if d.maxlen > 300:
+        pytest.skip("window too large for a quick differential run")
+    assert d.n_efn_sites == 2 and d.efn2data
+    sc = R.Scanner(d)
+    s = _planted_sequence(rng, 8_000)
+    want = oracle_scan(d, [s])
+    if want.shape[0] > 200_000:
+        pytest.skip("too many candidates for a quick run")
+    got = sc.scan(sc.database([s]))
+    assert got.shape == want.shape, text
+    assert np.array_equal(got, want), text
