@@ -45,3 +45,24 @@ def test_descriptor_errors_are_reported_not_fatal(built, tmp_path):
         R.Descriptor(["-descr", str(bad)])
     with pytest.raises(R.RnamotifError):
         R.Descriptor(["-descr", str(tmp_path / "missing.descr")])
+
+
+def test_author_corpus_compiles(built):
+    """61 of the 62 descriptors of descr/ compile; ps.3 is a syntax error by
+    design.  (Their scans are compared with the oracle on the GPU, tests/test_gpu_parity.py.)"""
+    import rnamotif_amd as R
+    d = os.path.join(ROOT, "tests", "golden", "descr")
+    cwd = os.getcwd()
+    os.chdir(d)
+    try:
+        bad = []
+        names = sorted(f for f in os.listdir(".") if f.endswith(".descr"))
+        for n in names:
+            try:
+                R.Descriptor(["-descr", n])
+            except R.RnamotifError as e:
+                bad.append((n, str(e)))
+    finally:
+        os.chdir(cwd)
+    assert len(names) == 62
+    assert [b[0] for b in bad] == ["ps.3.descr"] and "syntax error" in bad[0][1]
