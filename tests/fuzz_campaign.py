@@ -1,0 +1,53 @@
+"""Not a test: a longer differential campaign over the descriptor generators of
+tests/test_gpu_parity.py (GPU scanner against the oracle, a third of the cases with small tiles
+and a small work queue).  Run on the GPU box from the repository root:
+
+    python tests/fuzz_campaign.py lean 160 3000 ; python tests/fuzz_campaign.py general 40 3000
+
+Round 1: 2264 lean and 2835 general descriptors, no mismatch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, rnamotif_amd as R
+import test_gpu_parity as T
+from oracle_binding import oracle_scan
+kind, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+bad = ran = 0
+t0 = time.time()
+for seed in range(lo, hi):
+    rng = np.random.default_rng((1000 if kind == "lean" else 5000) + seed)
+    text = T._random_descriptor(rng) if kind == "lean" else T._random_general_descriptor(rng)
+    open("/tmp/f.descr", "w").write(text)
+    argv = ["-descr", "/tmp/f.descr"]
+    if kind != "lean" and seed % 2:
+        argv = ["-sh", "-context", "-Dctx_maxlen=4"] + argv
+    try:
+        d = R.Descriptor(argv)
+    except R.RnamotifError:
+        continue
+    if d.maxlen > (400 if kind == "lean" else 160):
+        continue
+    s = T._planted_sequence(rng, 6000)
+    seqs = [s, s[:301], s[:d.maxlen], s[:d.minlen]]
+    want = oracle_scan(d, seqs)
+    if want.shape[0] > 300000:
+        continue
+    if seed % 3 == 0:
+        os.environ["RNAMOTIF_TILE"] = "512"; os.environ["RNAMOTIF_QCAP"] = "128"
+    else:
+        os.environ.pop("RNAMOTIF_TILE", None); os.environ.pop("RNAMOTIF_QCAP", None)
+    try:
+        sc = R.Scanner(d)
+    except R.RnamotifError:
+        continue
+    got = sc.scan(sc.database(seqs))
+    ran += 1
+    if got.shape != want.shape or not np.array_equal(got, want):
+        bad += 1
+        print("MISMATCH", kind, seed, got.shape, want.shape, flush=True)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "fuzz_bad_%s_%d.descr" % (kind, seed)), "w").write(text)
+    if time.time() - t0 > 240:
+        print("time budget reached at seed", seed, flush=True)
+        break
+print(kind, "ran", ran, "bad", bad, "in %.0f s" % (time.time() - t0), flush=True)
