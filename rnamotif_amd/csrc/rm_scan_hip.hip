@@ -42,6 +42,7 @@ struct DbView {
 	const int64_t	*base_off;	// [n_seq]   first base of sequence s (multiple of 32)
 	const int32_t	*slen;		// [n_seq]
 	const int64_t	*tile_start;	// [n_seq+1] prefix sum of tiles over sequences
+	const int32_t	*tile_seq;	// [n_tiles] sequence of every tile (saves a search per tile)
 	const int32_t	*pos_lo, *pos_hi;	// [n_seq] or null: only start positions lo <= szero < hi (each strand)
 	int32_t	n_seq, strands, tile_t;
 	int64_t	n_tiles;
@@ -231,19 +232,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	for( ; ; ){
 		if( tid == 0 ){
 			long long	t = ( long long )atomicAdd( hb.ticket, 1ull );
-			int	s = 0;
-			if( t < db.n_tiles ){
-				// last sequence whose first tile is <= t
-				int	lo = 0, hi = db.n_seq - 1;
-				while( lo < hi ){
-					int	mid = ( lo + hi + 1 ) >> 1;
-					if( db.tile_start[ mid ] <= t )
-						lo = mid;
-					else
-						hi = mid - 1;
-				}
-				s = lo;
-			}
+			const int	s = t < db.n_tiles ? db.tile_seq[ t ] : 0;
 			s_tile = t;
 			s_seq = s;
 			s_qn = 0;
@@ -697,6 +686,7 @@ struct rma_db {
 	rma_scanner	*sc;
 	uint32_t	*d_codes = nullptr, *d_amask = nullptr;
 	int64_t	*d_base_off = nullptr, *d_tile_start = nullptr;
+	int32_t	*d_tile_seq = nullptr;
 	int32_t	*d_slen = nullptr, *d_pos_lo = nullptr, *d_pos_hi = nullptr;
 	int32_t	n_seq = 0;
 	int64_t	n_tiles = 0, total_bases = 0;
@@ -962,6 +952,14 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 		HIPCHK( hipMemcpy( db->d_slen, slen, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
 	}
 	HIPCHK( hipMemcpy( db->d_tile_start, tile_start.data(), tile_start.size() * sizeof( int64_t ), hipMemcpyHostToDevice ) );
+	{
+		std::vector<int32_t>	tile_seq( size_t( std::max<int64_t>( db->n_tiles, 1 ) ) );
+		for( int i = 0; i < n; i++ )
+			for( int64_t t = tile_start[ i ]; t < tile_start[ i + 1 ]; t++ )
+				tile_seq[ size_t( t ) ] = i;
+		HIPCHK( hipMalloc( &db->d_tile_seq, tile_seq.size() * sizeof( int32_t ) ) );
+		HIPCHK( hipMemcpy( db->d_tile_seq, tile_seq.data(), tile_seq.size() * sizeof( int32_t ), hipMemcpyHostToDevice ) );
+	}
 	if( pos_lo != nullptr && n > 0 ){
 		HIPCHK( hipMalloc( &db->d_pos_lo, size_t( n ) * sizeof( int32_t ) ) );
 		HIPCHK( hipMalloc( &db->d_pos_hi, size_t( n ) * sizeof( int32_t ) ) );
@@ -1028,6 +1026,7 @@ extern "C" void rma_db_destroy( rma_db_t *db )
 	( void )hipFree( db->d_base_off );
 	( void )hipFree( db->d_slen );
 	( void )hipFree( db->d_tile_start );
+	( void )hipFree( db->d_tile_seq );
 	( void )hipFree( db->d_pos_lo );
 	( void )hipFree( db->d_pos_hi );
 	delete db;
@@ -1043,6 +1042,7 @@ static DbView view_of( const rma_scanner *sc, const rma_db *db )
 	v.base_off = db->d_base_off;
 	v.slen = db->d_slen;
 	v.tile_start = db->d_tile_start;
+	v.tile_seq = db->d_tile_seq;
 	v.pos_lo = db->d_pos_lo;
 	v.pos_hi = db->d_pos_hi;
 	v.n_seq = db->n_seq;
