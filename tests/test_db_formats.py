@@ -103,7 +103,7 @@ def test_batch_boundaries_do_not_show(built, workdir, gbrna):
     outs = []
     for bb in ("1000000000", "3000"):
         env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"), RNAMOTIF_BATCH_BASES=bb)
-        p = subprocess.run([built["oracle_cli"], "-descr", "getbest.descr", "-N", "2000", gbrna], cwd=workdir, env=env,
+        p = subprocess.run([built["oracle_cli"], "-descr", "getbest.descr", "-N", "400", gbrna], cwd=workdir, env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         assert p.returncode == 0, p.stderr.decode()
         outs.append(p.stdout)

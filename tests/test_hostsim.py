@@ -29,8 +29,9 @@ def hostsim():
 CASES = [(["-descr", "trna.descr"], 1351), (["-descr", "mp.ends.descr"], 580), (["-descr", "qu+tr.descr"], 9),
          (["-descr", "pk_j1+2.descr"], 32), (["-descr", "bulge.descr"], 686), (["-descr", "nanlin.descr"], 13),
          (["-sh", "-context", "-Dctx_maxlen=5", "-descr", "qu+tr.strict.descr"], 9),
-         (["-sh", "-context", "-Dctx_maxlen=5", "-descr", "trna.strict.descr"], 184),
-         (["-sh", "-context", "-Dctx_maxlen=5", "-descr", "pk1.strict.descr"], 45)]
+         (["-sh", "-context", "-Dctx_maxlen=5", "-descr", "trna.strict.descr"], 184)]
+# (pk1 with -sh takes 25 s here; it is pinned through the oracle in test_golden_stdout.py and
+# compared on the GPU in test_gpu_parity.py)
 
 
 @pytest.mark.parametrize("args,ncand", CASES, ids=[" ".join(c[0][-1:]) for c in CASES])
