@@ -180,18 +180,33 @@ struct TailAccel {
 #ifndef GENERAL_WAVES_PER_SIMD
 #define GENERAL_WAVES_PER_SIMD	6
 #endif
-template< int BLOCK, bool LEAN >
+#ifndef SHORT_GROUP
+#define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
+#endif
+#define SHORT_ENTRY_MEAN	3000	// ... which are those whose entries average less than this
+// G: tiles per workgroup pass.  G == 1: one tile, all lanes on it.  G > 1 (databases of short
+// entries, lean descriptors only): a group of G small tiles, each in its own LDS slot and
+// pre-filtered by one wave, feeding ONE work queue -- a tile of a 500 base entry yields a few
+// dozen items, far too few for 256 lanes, and pass B is where the time goes.
+template< int BLOCK, bool LEAN, int G >
 __global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES_PER_SIMD )
 rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
+	static_assert( G == 1 || ( LEAN && G % ( BLOCK / 64 ) == 0 && G <= 32 ), "tile groups: lean path, whole rounds of waves" );
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
 	// gP is the compact image (rmd_make_image): prog_bytes of it, a multiple of 16
 	unsigned	*queue = reinterpret_cast<unsigned *>( smem + prog_bytes );
-	uint8_t	*tile = smem + prog_bytes + qcap * sizeof( unsigned );
+	uint8_t	*const tile0 = smem + prog_bytes + qcap * sizeof( unsigned );
+	const int	slot_bytes = ( tile_bytes + 15 ) & ~15;
 	__shared__ long long	s_tile;
 	__shared__ int	s_seq, s_qn, s_qhead;
+	__shared__ int	s_ctx[ G ][ G > 1 ? 8 : 1 ];	// G > 1: seq, comp, slen, z0, p_lo, vec_words of every slot
 	const int	tid = threadIdx.x;
+	// lanes that share a tile in pass A: the workgroup, or one wave per slot
+	constexpr int	UNIT = G > 1 ? 64 : BLOCK;
+	const int	utid = G > 1 ? ( tid & 63 ) : tid;
+	const int	ubase = G > 1 ? 0 : ( tid >> 6 ) * 64;
 
 	for( unsigned i = tid; i < unsigned( prog_bytes ) / 4; i += BLOCK )
 		reinterpret_cast<uint32_t *>( P )[ i ] = reinterpret_cast<const uint32_t *>( gP )[ i ];
@@ -218,10 +233,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const bool	e0_at_szero = e0.type == RMA_T_P5 || e0.type == RMA_T_T1 || e0.type == RMA_T_Q1 ||
 		( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
 	const int	pb_words = ( tile_bytes + 63 ) / 64 + 3;
-	unsigned long long	*pb = reinterpret_cast<unsigned long long *>( smem + prog_bytes + qcap * sizeof( unsigned ) +
-		( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) );
-	unsigned long long	*occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
-	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( occ + pb_words );
+	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
+	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * 6 * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
 	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
@@ -229,10 +242,11 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
 	const bool	split_ranks = !quick && lit && n_rank > 1 && n_rank < 0xffff;
 
+	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
 	for( ; ; ){
 		if( tid == 0 ){
-			long long	t = ( long long )atomicAdd( hb.ticket, 1ull );
-			const int	s = t < db.n_tiles ? db.tile_seq[ t ] : 0;
+			const long long	t = ( long long )atomicAdd( hb.ticket, 1ull );
+			const int	s = G == 1 && t < db.n_tiles ? db.tile_seq[ t ] : 0;
 			s_tile = t;
 			s_seq = s;
 			s_qn = 0;
@@ -240,30 +254,48 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		}
 		__syncthreads();
 		const long long	t = s_tile;
-		if( t >= db.n_tiles )
+		if( t >= n_units )
 			break;
-		const int	seq = s_seq;
-		const int	slen = db.slen[ seq ];
+		// what pass B needs of the tile (G > 1: of the last slot; pass B reloads per item)
+		int	seq = 0, slen = 0, z0 = 0, p_lo = 0, vec_words = 0;
+		uint8_t	*tile = tile0;
+		unsigned long long	*pb = pb0;
+		rmd_seq_t	sq{ tile0, 0 };
+		DevSink	sink{ hb, 0, 0, P->hit_stride };
+		const int	lane_id = tid & 63;
+		const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
+		// (every wave makes the same number of rounds: the barriers below stay legal)
+		for( int slot = G > 1 ? ( tid >> 6 ) : 0; slot < G; slot += G > 1 ? BLOCK / 64 : 1 ){
+		const long long	tt = G > 1 ? t * G + slot : t;
+		const bool	live = tt < db.n_tiles;
+		const unsigned	slot_bits = G > 1 ? unsigned( slot ) << 26 : 0u;
+		seq = G > 1 ? ( live ? db.tile_seq[ tt ] : 0 ) : s_seq;
+		slen = db.slen[ seq ];
+		tile = tile0 + size_t( slot ) * slot_bytes;
+		pb = pb0 + size_t( slot ) * 6 * pb_words;
+		unsigned long long	*const occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
 		const int64_t	off = db.base_off[ seq ];
-		const int	local = int( t - db.tile_start[ seq ] );
-		const int	per_strand = int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands );
+		const int	local = live ? int( tt - db.tile_start[ seq ] ) : 0;
+		const int	per_strand = live ? int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands ) : 1;
 		const int	comp = local / per_strand;
 		const int	pos_lo = db.pos_lo ? db.pos_lo[ seq ] : 0;
 		const int	pos_hi = db.pos_hi ? db.pos_hi[ seq ] : 0x7fffffff;
-		const int	z0 = pos_lo + ( local % per_strand ) * T;
+		z0 = pos_lo + ( local % per_strand ) * T;
 
 		// decode the bases this tile can touch: [ z0 - lm, z0 + T + w - 1 + rm )
-		const int	p_lo = z0 - lm;
+		p_lo = z0 - lm;
 		int	p_from = p_lo < 0 ? 0 : p_lo;
 		int	p_to = z0 + T + w - 1 + rm;
 		if( p_to > slen )
 			p_to = slen;
+		if( !live )
+			p_to = p_from;		// slot past the last tile: nothing to decode, no start position
 		// one packed word (16 bases) per lane and step; the reverse strand is the same words
 		// read backwards and complemented (mk_rcmp, rnamot.c:193)
 		if( p_from < p_to ){
 			const int	f_lo = comp ? slen - p_to : p_from, f_hi = comp ? slen - 1 - p_from : p_to - 1;
 			const int64_t	w_lo = ( off + f_lo ) >> 4, w_hi = ( off + f_hi ) >> 4;
-			for( int64_t wi = w_lo + tid; wi <= w_hi; wi += BLOCK ){
+			for( int64_t wi = w_lo + utid; wi <= w_hi; wi += UNIT ){
 				const uint32_t	cw = db.codes[ wi ];
 				const uint32_t	am = db.amask[ wi >> 1 ] >> ( ( wi & 1 ) * 16 );
 				const int	f0 = int( ( wi << 4 ) - off );
@@ -281,25 +313,30 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		__syncthreads();
 		// short entries fill only part of a tile: the loops below run over what is there
 		const int	pos_end = rmd_imin( slen - P->dminlen + 1, pos_hi );
-		const int	n_pos = rmd_imin( T, pos_end - z0 );			// start positions of this tile
-		const int	vec_words = rmd_imin( pb_words, ( p_to - p_lo + 64 + 63 ) / 64 + 1 );	// bit vector words in use
+		const int	n_pos = live ? rmd_imin( T, pos_end - z0 ) : 0;		// start positions of this tile
+		vec_words = rmd_imin( pb_words, ( p_to - p_lo + 64 + 63 ) / 64 + 1 );	// bit vector words in use
+		if constexpr( G > 1 ){
+			if( utid == 0 ){
+				int	*c = s_ctx[ slot ];
+				c[ 0 ] = seq; c[ 1 ] = comp; c[ 2 ] = slen; c[ 3 ] = z0; c[ 4 ] = p_lo; c[ 5 ] = vec_words;
+			}
+		}
 
 		// ---- pass A: pre-filter.  Where the first search element is a proper helix
 		// or a 4-plex, almost every (start, end) pair dies at its first base pairs
 		// (find_motif.c:1010-1021); test that here in registers, no search state,
 		// and compact the survivors into the LDS work queue with one wave ballot +
 		// prefix count per step.  Other first elements queue the whole position.
-		rmd_seq_t	sq{ tile, p_lo };
-		DevSink	sink{ hb, seq, comp, P->hit_stride };
-		const int	lane_id = tid & 63;
-		const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
+		sq = rmd_seq_t{ tile, p_lo };
+		sink.seq = seq;
+		sink.comp = comp;
 		// Best-literal filter (the reference's -O skip scan, find_motif.c:209-243, as a
 		// necessary condition): occ has a bit for every tile position where the literal
 		// starts; a start position is searched only if one lies at an allowed offset.
 		if( lit ){
 			const rmd_regex_t	&lre = rmd_regexes( P )[ P->lit_re ];
 			const int	n_valid = p_to - p_lo;
-			for( int base = ( tid >> 6 ) * 64; base < vec_words * 64; base += BLOCK ){
+			for( int base = ubase; base < vec_words * 64; base += UNIT ){
 				const int	q = base + lane_id - 64;
 				bool	ok = q >= p_from - p_lo && q + lit_n <= n_valid;
 				for( int jj = 0; ok && jj < lit_n; jj++ )
@@ -338,7 +375,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			if( pred ){ \
 				const int	slot_ = base_ + __popcll( m_ & lt_mask ); \
 				if( slot_ < qcap ) \
-					queue[ slot_ ] = ( item ); \
+					queue[ slot_ ] = ( item ) | slot_bits; \
 				else if constexpr( LEAN ){ \
 					rmd_lean_t	st_; \
 					int	k_ = rmd_lean_begin( P, lr, st_, szero_, slen, r0_, cnt_ ); \
@@ -355,7 +392,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			// (start, end) all pair" is an AND of minlen shifted 64-bit windows, 64 end
 			// positions at a time.
 			const int	n_valid = p_to - p_lo;
-			for( int base = ( tid >> 6 ) * 64; base < vec_words * 64; base += BLOCK ){
+			for( int base = ubase; base < vec_words * 64; base += UNIT ){
 				const int	q = base + lane_id - 64;		// one pad word in front
 				const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
 				for( int b5 = 0; b5 < 5; b5++ ){
@@ -414,8 +451,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					W = imin >= 64 ? 0 : W & ( ~0ull << imin );
 				return W;
 			};
-			for( int j = 0; j < n_pos; j += BLOCK ){
-				const int	rel = j + tid;
+			for( int j = 0; j < n_pos; j += UNIT ){
+				const int	rel = j + utid;
 				const int	szero = z0 + rel;
 				bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
 				if( valid )
@@ -470,8 +507,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 			}
 		}else
-		for( int j = 0; j < n_pos; j += BLOCK ){
-			const int	rel = j + tid;
+		for( int j = 0; j < n_pos; j += UNIT ){
+			const int	rel = j + utid;
 			const int	szero = z0 + rel;
 			bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
 			if( valid )
@@ -517,6 +554,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 #undef QPUSH
 #undef LIT_OK
 #undef LIT_IN
+		}	// slots
 		__syncthreads();
 
 		// ---- pass B: the full search.  Lanes are persistent within the tile: a lane
@@ -529,6 +567,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		int	k = -1;
 		bool	dry = false;
 		if constexpr( LEAN ){
+
 			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
 			rmd_lean_t	st;
 			// the pre-filter's rows serve the tail test of level 0 when the tail helix pairs by
@@ -556,7 +595,24 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						if( i < nq ){
 							const unsigned	item = queue[ i ];
 							const int	r = int( item & 0xffffu );
-							const int	szero = z0 + int( item >> 16 );
+							if constexpr( G > 1 ){
+								// the item's own tile: its slot of LDS, its entry and strand
+								const int	sl = int( item >> 26 );
+								const int	*c = s_ctx[ sl ];
+								slen = c[ 2 ];
+								z0 = c[ 3 ];
+								p_lo = c[ 4 ];
+								tile = tile0 + size_t( sl ) * slot_bytes;
+								pb = pb0 + size_t( sl ) * 6 * pb_words;
+								sq = rmd_seq_t{ tile, p_lo };
+								sink.seq = c[ 0 ];
+								sink.comp = c[ 1 ];
+								accel.pb = pb;
+								accel.tile = tile;
+								accel.p_lo = p_lo;
+								accel.vec_bits = c[ 5 ] * 64;
+							}
+							const int	szero = z0 + int( ( item >> 16 ) & ( G > 1 ? 0x3ffu : 0xffffu ) );
 							bool	drop = false;
 							if( accel.usable_for >= 0 && r != 0xffff ){
 								// the tail test for every helix length the end position allows,
@@ -687,6 +743,7 @@ struct rma_db {
 	uint32_t	*d_codes = nullptr, *d_amask = nullptr;
 	int64_t	*d_base_off = nullptr, *d_tile_start = nullptr;
 	int32_t	*d_tile_seq = nullptr;
+	int	tile_t = 0, qcap = 0, group = 1;	// launch shape of this database (see db_upload)
 	int32_t	*d_slen = nullptr, *d_pos_lo = nullptr, *d_pos_hi = nullptr;
 	int32_t	n_seq = 0;
 	int64_t	n_tiles = 0, total_bases = 0;
@@ -740,11 +797,12 @@ extern "C" int rma_device_count( void )
 }
 
 // LDS of one search workgroup: program image | queue | tile | 6 bit vectors | lean records
-static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap )
+static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1 )
 {
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
 	const size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
-	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) + ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes;
+	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
+		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	if( lean )
 		lds += size_t( dp.n_searches ) * 256 * LEAN_REC_BYTES;
 	return lds;
@@ -923,7 +981,38 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 	db->total_bases = 0;
 	db->strands = sc->prog.chk_both_strs ? 2 : 1;
 	std::vector<int64_t>	tile_start( size_t( n ) + 1, 0 );
-	const int	T = sc->tile_t;
+	// Launch shape.  Long entries: the scanner's tile, one per workgroup pass.  A database of
+	// many short entries (GenBank divisions, transcript sets) never fills such a tile, and a
+	// few dozen queue items cannot occupy 256 lanes: it gets small tiles in groups of
+	// SHORT_GROUP per workgroup pass (rma_search_kernel<.., G>), if the descriptor is lean and
+	// the group fits the LDS budget.
+	db->tile_t = sc->tile_t;
+	db->qcap = sc->qcap;
+	db->group = 1;
+	{
+		int64_t	tot = 0;
+		for( int i = 0; i < n; i++ )
+			tot += slen[ i ];
+		bool	grouped = n >= 64 && tot / n < SHORT_ENTRY_MEAN && !getenv( "RNAMOTIF_TILE" );
+		if( const char *force = getenv( "RNAMOTIF_SHORT" ) )	// "0" never, "1" always (tests)
+			grouped = force[ 0 ] == '1';
+		if( grouped && sc->dprog.lean_ok ){
+			const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64 - SHORT_GROUP * 32;
+			const double	per_pos = double( sc->qcap ) / sc->tile_t;
+			for( int t = 1024; t >= 256; t -= 256 ){
+				int	q = std::max( 256, int( std::ceil( per_pos * t * SHORT_GROUP / 256 ) ) * 256 );
+				if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )	// tests: force the overflow path
+					q = std::max( 64, atoi( qq ) );
+				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true, q, SHORT_GROUP ) <= budget ){
+					db->tile_t = t;
+					db->qcap = q;
+					db->group = SHORT_GROUP;
+					break;
+				}
+			}
+		}
+	}
+	const int	T = db->tile_t;
 	for( int i = 0; i < n; i++ ){
 		int64_t	nsz = int64_t( slen[ i ] ) - sc->prog.dminlen + 1;	// start positions of a strand
 		if( pos_lo != nullptr ){
@@ -1047,7 +1136,7 @@ static DbView view_of( const rma_scanner *sc, const rma_db *db )
 	v.pos_hi = db->d_pos_hi;
 	v.n_seq = db->n_seq;
 	v.strands = db->strands;
-	v.tile_t = sc->tile_t;
+	v.tile_t = db->tile_t;
 	v.n_tiles = db->n_tiles;
 	return v;
 }
@@ -1074,27 +1163,33 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	const rmd_program_t	&dp = sc->dprog;
 	const int	dbg = getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0;
 	const bool	lean = dp.lean_ok && !( dbg & 16 );
-	int	tile_bytes = sc->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	size_t	lds = search_lds_bytes( sc->prog_bytes, dp, sc->tile_t, lean, sc->qcap );
+	const bool	grouped = lean && db->group > 1;
+	int	tile_bytes = db->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
+	size_t	lds = search_lds_bytes( sc->prog_bytes, dp, db->tile_t, lean, db->qcap, grouped ? SHORT_GROUP : 1 );
 	if( lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;
 	}
-	HIPCHK( hipFuncSetAttribute( lean ? reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, true> ) :
-		reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, false> ),
+	HIPCHK( hipFuncSetAttribute( grouped ? reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, true, SHORT_GROUP> ) :
+		lean ? reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, true, 1> ) :
+		reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, false, 1> ),
 		hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	int	grid = int( std::min<int64_t>( db->n_tiles, sc->grid_blocks ) );
+	const int64_t	n_units = grouped ? ( db->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : db->n_tiles;
+	int	grid = int( std::min<int64_t>( n_units, sc->grid_blocks ) );
 	unsigned long long	count = 0;
 	for( int attempt = 0; attempt < 2; attempt++ ){
 		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 4 * sizeof( unsigned long long ), sc->stream ) );
 		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
-		if( lean )
-			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, sc->prog_bytes, sc->qcap, v, hb, tile_bytes, dbg );
+		if( grouped )
+			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true, SHORT_GROUP> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
+				sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
+		else if( lean )
+			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true, 1> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
+				sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
 		else
-			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, false> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, sc->prog_bytes, sc->qcap, v, hb, tile_bytes, dbg );
+			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, false, 1> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
+				sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );
@@ -1102,7 +1197,8 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		if( getenv( "RNAMOTIF_DBG" ) ){
 			unsigned long long	q = 0;
 			( void )hipMemcpy( &q, sc->d_counters + 2, sizeof( q ), hipMemcpyDeviceToHost );
-			fprintf( stderr, "[dbg] queued items: %llu, candidates %llu\n", q, count );
+			fprintf( stderr, "[dbg] queued items: %llu, candidates %llu (tile %d x %d, queue %d, LDS %zu, %lld tiles)\n", q, count,
+				db->tile_t, grouped ? db->group : 1, db->qcap, lds, ( long long )db->n_tiles );
 		}
 		if( int64_t( count ) <= sc->hit_cap )
 			break;

@@ -123,6 +123,28 @@ def _descr(workdir, name, extra=()):
         os.chdir(cwd)
 
 
+class _env:
+    """Environment variables for the duration of a with block (launch-shape overrides)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 SYN_DESCR = ["trna.descr", "pk1.descr", "pk_j1+2.descr", "qu+tr.descr", "ire.descr", "mp.ends.descr",
              "bulge.descr", "nanlin.descr", "score.1.descr", "sprintf.descr"]
 
@@ -194,6 +216,33 @@ def test_tile_sizes_agree(built, workdir):
             os.environ["RNAMOTIF_TILE"] = old
     for r in res[1:]:
         assert np.array_equal(res[0], r)
+
+
+@pytest.mark.parametrize("name", ["trna.descr", "mp.ends.descr", "bulge.descr", "ire.descr", "score.1.descr", "efn.descr"])
+def test_grouped_tiles_agree(built, workdir, gbrna, name):
+    """Databases of short entries are searched in groups of small tiles that share one work
+    queue (rma_search_kernel<.., G>); the choice is a launch shape only.  The reference's test
+    database (4000 entries of 560 bases on average) and random entries of awkward lengths, one
+    tile per pass against grouped, with an ample queue and with one that overflows."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    d = _descr(workdir, name)
+    rng = np.random.default_rng(14)
+    lut = np.frombuffer(b"acgtn", dtype=np.uint8)
+    lens = [0, 1, 33, 70, 71, 72, 73, 200, 511, 512, 513, 767, 768, 769, 1023, 1024, 1025, 1100, 2047, 2049, 40_000]
+    syn = [lut[rng.choice(5, size=n, p=[0.25, 0.25, 0.25, 0.24, 0.01])].tobytes() for n in lens * 4]
+    for seqs, check_oracle in (([r[2] for r in R.read_fasta(gbrna)], False), (syn, True)):
+        res = []
+        for short, qcap in (("0", None), ("1", None), ("1", 64)):
+            with _env(RNAMOTIF_SHORT=short, RNAMOTIF_QCAP=qcap):
+                sc = R.Scanner(d)
+                res.append(sc.scan(sc.database(seqs)))
+        assert res[0].shape[0] > 0 or name == "ire.descr"
+        for r in res[1:]:
+            assert r.shape == res[0].shape and np.array_equal(r, res[0])
+        if check_oracle:
+            want = oracle_scan(d, seqs)
+            assert want.shape == res[0].shape and np.array_equal(want, res[0])
 
 
 SYN10M_FIRST_TRNA = (b"syn0000         1.981  -12.300 0   59767   82 cgagcc tt ctt taca gag a catg acggaac catg "
@@ -475,6 +524,13 @@ def test_random_descriptors_equal_oracle(built, tmp_path, seed):
     if want.shape[0] > 400_000:
         pytest.skip("too many candidates for a quick run")
     got = sc.scan(sc.database(seqs))
+    assert got.shape == want.shape, text
+    assert np.array_equal(got, want), text
+    # the same entries cut into pieces, as a database of short entries (groups of small tiles)
+    pieces = [bytes(s[a:a + int(ln)]) for a, ln in zip(range(0, n - 900, 700), rng.integers(0, 900, size=64))]
+    want = oracle_scan(d, pieces)
+    with _env(RNAMOTIF_SHORT="1", RNAMOTIF_QCAP=(64 if seed % 2 else None)):
+        got = sc.scan(sc.database(pieces))
     assert got.shape == want.shape, text
     assert np.array_equal(got, want), text
 
