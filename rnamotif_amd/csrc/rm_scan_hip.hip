@@ -241,6 +241,17 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const int	lit_n = lit ? rmd_regexes( P )[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
 	const bool	split_ranks = !quick && lit && n_rank > 1 && n_rank < 0xffff;
+	// TailAccel applies: symmetric pair table, tail helix on the same table without mispairs
+	bool	tail_from_rows = false;
+	if( LEAN && bitpar && e0.tail_s >= 0 ){
+		const rmd_elem_t	&te = P->elems[ P->searches[ e0.tail_s ] ];
+		bool	sym = true;
+		for( int x = 0; x < 5; x++ )
+			for( int y = 0; y < 5; y++ )
+				sym = sym && ( ( ( e0_mat2 >> ( x * 5 + y ) ) ^ ( e0_mat2 >> ( y * 5 + x ) ) ) & 1 ) == 0;
+		tail_from_rows = sym && te.pairset == e0.pairset && te.mplim == 0 && !te.pfrac && te.minlen >= 1 &&
+			( te.ends & RMA_5PAIRED ) && ( te.ends & RMA_3PAIRED ) && te.maxglen != RMA_UNBOUNDED;
+	}
 
 	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
 	for( ; ; ){
@@ -572,17 +583,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			rmd_lean_t	st;
 			// the pre-filter's rows serve the tail test of level 0 when the tail helix pairs by
 			// the same (symmetric) table, allows no mispair and has both ends paired
-			TailAccel	accel{ P, pb, tile, pb_words, p_lo, vec_words * 64, -1 };
-			if( bitpar && e0.tail_s >= 0 ){
-				const rmd_elem_t	&te = P->elems[ P->searches[ e0.tail_s ] ];
-				bool	sym = true;
-				for( int x = 0; x < 5; x++ )
-					for( int y = 0; y < 5; y++ )
-						sym = sym && ( ( ( e0_mat2 >> ( x * 5 + y ) ) ^ ( e0_mat2 >> ( y * 5 + x ) ) ) & 1 ) == 0;
-				if( sym && te.pairset == e0.pairset && te.mplim == 0 && !te.pfrac && te.minlen >= 1 &&
-					( te.ends & RMA_5PAIRED ) && ( te.ends & RMA_3PAIRED ) && te.maxglen != RMA_UNBOUNDED )
-					accel.usable_for = 0;
-			}
+			TailAccel	accel{ P, pb, tile, pb_words, p_lo, vec_words * 64, tail_from_rows ? 0 : -1 };
 			for( ; ; ){
 				// lanes without work pop until they hold an item that survives the tail test
 				for( unsigned long long want; ( want = __ballot( k < 0 && !dry ) ) != 0; ){

@@ -271,6 +271,38 @@ def test_syn10m_cli_hit_counts(built, workdir, tmp_path_factory, name):
         assert b" ".join(first.split()) == b" ".join(SYN10M_FIRST_TRNA.split())
 
 
+@pytest.mark.parametrize("name", ["trna.efn.descr", "mp.ends.descr"])
+def test_full_size_properties(built, workdir, name):
+    """BASELINE.json's headline size (100 records of 1 Mbase, the bench workload), where the
+    oracle would take minutes: properties that hold at any size.  (1) Shards add up: the two
+    halves of the database scanned separately are the whole scan.  (2) Strands mirror: the
+    reverse complement of every record gives the same candidates with the strand flag flipped
+    (offsets in a record are strand local).  (3) Sorted, no duplicates."""
+    import rnamotif_amd as R
+    d = _descr(workdir, name)
+    seqs = R.synthetic_records(100)
+    sc = R.Scanner(d)
+    whole = sc.scan(sc.database(seqs))
+    assert whole.shape[0] > 100
+    key = whole[:, :5]
+    order = np.lexsort(key.T[::-1])
+    assert np.array_equal(order, np.arange(len(order))), "records are not in (seq, comp, szero, rank, order) order"
+    assert len(np.unique(key, axis=0)) == len(key)
+    # (1)
+    a = sc.scan(sc.database(seqs[:50]))
+    b = sc.scan(sc.database(seqs[50:]))
+    b[:, 0] += 50
+    assert np.array_equal(np.concatenate([a, b]), whole)
+    # (2)
+    tr = bytes.maketrans(b"acgt", b"tgca")
+    rc = [s.translate(tr)[::-1] for s in seqs]
+    del seqs
+    mirror = sc.scan(sc.database(rc))
+    mirror[:, 1] ^= 1
+    mirror = mirror[np.lexsort(mirror[:, :5].T[::-1])]
+    assert np.array_equal(mirror, whole)
+
+
 def test_start_position_ranges(built, workdir):
     """rma_db_create_ranges: slices of an entry's start positions searched separately (as
     different GPUs would) add up to the whole entry's records, cut anywhere."""
