@@ -3,8 +3,10 @@ tests/test_gpu_parity.py (GPU scanner against the oracle, a third of the cases w
 and a small work queue).  Run on the GPU box from the repository root:
 
     python tests/fuzz_campaign.py lean 160 3000 ; python tests/fuzz_campaign.py general 40 3000
+    python tests/fuzz_campaign.py grouped 160 3000     (lean descriptors, database cut into short
+                                                        entries, groups of small tiles forced)
 
-Round 1: 2264 lean and 2835 general descriptors, no mismatch."""
+Round 1: 4530 lean, 2835 general and 2183 grouped descriptors, no mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,25 +17,33 @@ kind, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 bad = ran = 0
 t0 = time.time()
 for seed in range(lo, hi):
-    rng = np.random.default_rng((1000 if kind == "lean" else 5000) + seed)
-    text = T._random_descriptor(rng) if kind == "lean" else T._random_general_descriptor(rng)
+    lean = kind in ("lean", "grouped")
+    rng = np.random.default_rng((1000 if lean else 5000) + seed)
+    text = T._random_descriptor(rng) if lean else T._random_general_descriptor(rng)
     open("/tmp/f.descr", "w").write(text)
     argv = ["-descr", "/tmp/f.descr"]
-    if kind != "lean" and seed % 2:
+    if not lean and seed % 2:
         argv = ["-sh", "-context", "-Dctx_maxlen=4"] + argv
     try:
         d = R.Descriptor(argv)
     except R.RnamotifError:
         continue
-    if d.maxlen > (400 if kind == "lean" else 160):
+    if d.maxlen > (400 if lean else 160):
         continue
     s = T._planted_sequence(rng, 6000)
     seqs = [s, s[:301], s[:d.maxlen], s[:d.minlen]]
+    if kind == "grouped":
+        cuts = np.sort(rng.integers(0, len(s), size=int(rng.integers(5, 40))))
+        seqs = [s[a:b] for a, b in zip(np.r_[0, cuts], np.r_[cuts, len(s)])] + [s[:1030], s[:1024 + d.maxlen], b""]
+        os.environ["RNAMOTIF_SHORT"] = "1"
     want = oracle_scan(d, seqs)
     if want.shape[0] > 300000:
         continue
     if seed % 3 == 0:
         os.environ["RNAMOTIF_TILE"] = "512"; os.environ["RNAMOTIF_QCAP"] = "128"
+        if kind == "grouped":
+            os.environ.pop("RNAMOTIF_TILE")     # (a forced tile size switches the groups off)
+            os.environ["RNAMOTIF_QCAP"] = "64"
     else:
         os.environ.pop("RNAMOTIF_TILE", None); os.environ.pop("RNAMOTIF_QCAP", None)
     try:
