@@ -253,6 +253,16 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			( te.ends & RMA_5PAIRED ) && ( te.ends & RMA_3PAIRED ) && te.maxglen != RMA_UNBOUNDED;
 	}
 
+	// a slot belongs to one wave when G > 1: its phases are ordered within the wave (LDS
+	// executes a wave's accesses in order), the waves need not march in step
+#define SLOT_SYNC()	do{ \
+		if constexpr( G > 1 ){ \
+			__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" ); \
+			__builtin_amdgcn_wave_barrier(); \
+			__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" ); \
+		}else \
+			__syncthreads(); \
+	}while( 0 )
 	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
 	for( ; ; ){
 		if( tid == 0 ){
@@ -275,7 +285,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		DevSink	sink{ hb, 0, 0, P->hit_stride };
 		const int	lane_id = tid & 63;
 		const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
-		// (every wave makes the same number of rounds: the barriers below stay legal)
+		// (every wave makes the same number of rounds)
 		for( int slot = G > 1 ? ( tid >> 6 ) : 0; slot < G; slot += G > 1 ? BLOCK / 64 : 1 ){
 		const long long	tt = G > 1 ? t * G + slot : t;
 		const bool	live = tt < db.n_tiles;
@@ -321,7 +331,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 			}
 		}
-		__syncthreads();
+		SLOT_SYNC();
 		// short entries fill only part of a tile: the loops below run over what is there
 		const int	pos_end = rmd_imin( slen - P->dminlen + 1, pos_hi );
 		const int	n_pos = live ? rmd_imin( T, pos_end - z0 ) : 0;		// start positions of this tile
@@ -356,7 +366,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( lane_id == 0 )
 					occ[ base >> 6 ] = m;
 			}
-			__syncthreads();
+			SLOT_SYNC();
 		}
 		// does the literal start anywhere in [a_, b_] (absolute positions)?
 #define LIT_IN( a_, b_, res_ )	do{ \
@@ -412,7 +422,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						pb[ b5 * pb_words + ( base >> 6 ) ] = m;
 				}
 			}
-			__syncthreads();
+			SLOT_SYNC();
 			const int	hl0 = e0.minlen;
 			// superset of match_wchlx's rule (find_motif.c:1010-1033,1065-1080): at most mplim
 			// mispairs among the first minlen pairs; an unpaired first pair is allowed only if
@@ -566,6 +576,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 #undef LIT_OK
 #undef LIT_IN
 		}	// slots
+#undef SLOT_SYNC
 		__syncthreads();
 
 		// ---- pass B: the full search.  Lanes are persistent within the tile: a lane
