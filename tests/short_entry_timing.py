@@ -27,7 +27,8 @@ def run(d, seqs, mode):
     return h, min(sc.scan_device(db)[1] for _ in range(5))
 
 
-for descr in sys.argv[1:] or ["descr/trna.descr", "test/mp.ends.descr", "test/bulge.descr", "test/ire.descr"]:
+for descr in sys.argv[1:] or ["descr/trna.descr", "test/mp.ends.descr", "test/bulge.descr", "test/ire.descr",
+                                "test/pk1.descr", "test/qu+tr.descr", "test/nanlin.descr"]:
     d = R.Descriptor(["-descr", os.path.join(ROOT, "tests/golden", descr)])
     h0, t0 = run(d, short, "0")
     h1, t1 = run(d, short, None)
