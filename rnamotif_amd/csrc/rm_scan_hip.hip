@@ -53,6 +53,8 @@ struct HitBuf {
 	unsigned long long	*count;		// candidates found (may exceed cap)
 	unsigned long long	*ticket;	// next tile
 	int64_t	cap;
+	unsigned	*spill;			// [gridDim.x][spill_cap] work queue items that did not fit the LDS queue
+	int	spill_cap;
 };
 
 __device__ inline int db_code( const DbView &db, int64_t base )	// forward strand code of absolute base
@@ -183,7 +185,8 @@ struct TailAccel {
 #ifndef SHORT_GROUP
 #define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
 #endif
-#define SHORT_ENTRY_MEAN	3000	// ... which are those whose entries average less than this
+#define SHORT_ENTRY_MEAN	3000
+#define SPILL_ITEMS		8192	// queue items per workgroup that may overflow into HBM (32 KB each, 64 MB in all)	// ... which are those whose entries average less than this
 // G: tiles per workgroup pass.  G == 1: one tile, all lanes on it.  G > 1 (databases of short
 // entries, lean descriptors only): a group of G small tiles, each in its own LDS slot and
 // pre-filtered by one wave, feeding ONE work queue -- a tile of a 500 base entry yields a few
@@ -263,6 +266,12 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		}else \
 			__syncthreads(); \
 	}while( 0 )
+	// Queue overflow (the queue is sized for the expected density; real sequence clusters) goes to
+	// this workgroup's spill area in HBM and is popped after the LDS part -- 4 bytes out and in
+	// per item, through L2 (agent scope: the area is reused tile after tile).  Only what exceeds
+	// that too is searched in place by the lane that found it.
+	unsigned	*const spill = hb.spill + size_t( blockIdx.x ) * hb.spill_cap;
+	const int	qtotal = qcap + hb.spill_cap;
 	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
 	for( ; ; ){
 		if( tid == 0 ){
@@ -397,6 +406,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				const int	slot_ = base_ + __popcll( m_ & lt_mask ); \
 				if( slot_ < qcap ) \
 					queue[ slot_ ] = ( item ) | slot_bits; \
+				else if( slot_ < qtotal ) \
+					__hip_atomic_store( spill + ( slot_ - qcap ), ( item ) | slot_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); \
 				else if constexpr( LEAN ){ \
 					rmd_lean_t	st_; \
 					int	k_ = rmd_lean_begin( P, lr, st_, szero_, slen, r0_, cnt_ ); \
@@ -583,7 +594,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		// that finishes its item pops the next one at once (wave-aggregated pop), so a
 		// wave lasts as long as its share of the work, not as its slowest item times
 		// the number of rounds.
-		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < qcap ? s_qn : qcap );
+		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < qtotal ? s_qn : qtotal );
 		if( ( dbg & 2 ) && tid == 0 )
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
 		int	k = -1;
@@ -605,7 +616,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					if( k < 0 && !dry ){
 						const int	i = base + __popcll( want & lt_mask );
 						if( i < nq ){
-							const unsigned	item = queue[ i ];
+							const unsigned	item = i < qcap ? queue[ i ] :
+								__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 							const int	r = int( item & 0xffffu );
 							if constexpr( G > 1 ){
 								// the item's own tile: its slot of LDS, its entry and strand
@@ -665,7 +677,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( k < 0 && !dry ){
 					const int	i = base + __popcll( want & lt_mask );
 					if( i < nq ){
-						const unsigned	item = queue[ i ];
+						const unsigned	item = i < qcap ? queue[ i ] :
+							__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 						const int	r = int( item & 0xffffu );
 						k = rmd_search_begin( P, &lane, z0 + int( item >> 16 ), slen,
 							r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
@@ -743,6 +756,8 @@ struct rma_scanner {
 	int32_t	*d_hits = nullptr;
 	int64_t	hit_cap = 0;
 	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
+	unsigned	*d_spill = nullptr;		// [grid_blocks][spill_cap] queue overflow of every workgroup
+	int	spill_cap = 0;
 	int32_t	*h_raw = nullptr;		// pinned
 	size_t	h_raw_cap = 0;
 	std::vector<int32_t>	h_sorted;
@@ -876,6 +891,10 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	hipDeviceProp_t	prop;
 	HIPCHK( hipGetDeviceProperties( &prop, device ) );
 	sc->grid_blocks = prop.multiProcessorCount * 8;
+	sc->spill_cap = SPILL_ITEMS;
+	if( const char *sp = getenv( "RNAMOTIF_SPILL" ) )	// tests: 0 = overflow searched in place
+		sc->spill_cap = std::max( 0, atoi( sp ) );
+	HIPCHK( hipMalloc( &sc->d_spill, std::max<size_t>( size_t( sc->grid_blocks ) * sc->spill_cap, 1 ) * sizeof( unsigned ) ) );
 	if( sc->dprog.lean_ok ){
 		// The search of a tile ends with a few long-running items on a few lanes, so fewer,
 		// larger tiles are better as long as four workgroups still share a CU's 160 KB of LDS
@@ -967,6 +986,7 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 	( void )hipFree( sc->d_loginc );
 	( void )hipFree( sc->d_hits );
 	( void )hipFree( sc->d_counters );
+	( void )hipFree( sc->d_spill );
 	for( int i = 0; i < 4; i++ )
 		if( sc->ev[ i ] )
 			( void )hipEventDestroy( sc->ev[ i ] );
@@ -1191,7 +1211,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	unsigned long long	count = 0;
 	for( int attempt = 0; attempt < 2; attempt++ ){
 		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 4 * sizeof( unsigned long long ), sc->stream ) );
-		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap };
+		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		if( grouped )
 			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true, SHORT_GROUP> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,

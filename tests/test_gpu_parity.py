@@ -234,8 +234,8 @@ def test_grouped_tiles_agree(built, workdir, gbrna, name):
     syn = [lut[rng.choice(5, size=n, p=[0.25, 0.25, 0.25, 0.24, 0.01])].tobytes() for n in lens * 4]
     for seqs, check_oracle in (([r[2] for r in R.read_fasta(gbrna)], False), (syn, True)):
         res = []
-        for short, qcap in (("0", None), ("1", None), ("1", 64)):
-            with _env(RNAMOTIF_SHORT=short, RNAMOTIF_QCAP=qcap):
+        for short, qcap, spill in (("0", None, None), ("1", None, None), ("1", 64, None), ("1", 64, 0), ("0", 64, 32)):
+            with _env(RNAMOTIF_SHORT=short, RNAMOTIF_QCAP=qcap, RNAMOTIF_SPILL=spill):
                 sc = R.Scanner(d)
                 res.append(sc.scan(sc.database(seqs)))
         assert res[0].shape[0] > 0 or not check_oracle or name in ("ire.descr", "pk_j1+2.descr", "qu+tr.descr", "nanlin.descr")
@@ -731,9 +731,12 @@ def test_random_descriptors_under_stress_settings(built, tmp_path, seed, gen):
     want = oracle_scan(d, seqs)
     if want.shape[0] > 300_000:
         pytest.skip("too many candidates for a quick run")
-    old = {k: os.environ.get(k) for k in ("RNAMOTIF_TILE", "RNAMOTIF_QCAP")}
+    old = {k: os.environ.get(k) for k in ("RNAMOTIF_TILE", "RNAMOTIF_QCAP", "RNAMOTIF_SPILL")}
     os.environ["RNAMOTIF_TILE"] = "256"
     os.environ["RNAMOTIF_QCAP"] = "64"
+    # what does not fit the queue spills to HBM, and what does not fit there is searched in place:
+    # no spill area at all, or one of 16 items
+    os.environ["RNAMOTIF_SPILL"] = "0" if seed % 2 else "16"
     try:
         try:
             sc = R.Scanner(d)
