@@ -44,12 +44,12 @@ def synthetic_slice(first: int, count: int, length: int):
 
 def profiled_traffic(kernel="rma_search_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (profiles/r01_final6_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE in
+    PMC passes (profiles/r01_final7_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE in
     separate passes over this same default workload, in KiB).  Corrected as
     MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies 128-byte
     requests at 64 bytes -> doubled; WRITE_SIZE is exact."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final6_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01_final7_pmc_summary.csv")
     if not os.path.exists(path):
         return None
     kb = {}
@@ -67,7 +67,7 @@ def profiled_issue(kernel_ms, kernel="rma_search_kernel"):
     measured now, against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per 64-wide VALU instruction;
     lanes = average active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU)."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final6_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01_final7_pmc_summary.csv")
     if not os.path.exists(path):
         return None
     c = {}
@@ -282,7 +282,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 8),
                 "traffic": profiled_traffic() if default_workload and world == 1 else None,
                 "traffic_note": "bytes per launch from the committed PMC passes of this workload "
-                                "(profiles/r01_final6_pmc_summary.csv), 2 x FETCH_SIZE + WRITE_SIZE",
+                                "(profiles/r01_final7_pmc_summary.csv), 2 x FETCH_SIZE + WRITE_SIZE",
                 "algorithmic_bytes": int(ALGO_BYTES_PER_BASE * bases_per_gpu * len(descrs)),
                 "kernel_ms": round(search_ms, 3),
                 "efn_kernel_ms": round(efn_ms, 3),

@@ -268,8 +268,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	}while( 0 )
 	// Queue overflow (the queue is sized for the expected density; real sequence clusters) goes to
 	// this workgroup's spill area in HBM and is popped after the LDS part -- 4 bytes out and in
-	// per item, through L2 (agent scope: the area is reused tile after tile).  Only what exceeds
-	// that too is searched in place by the lane that found it.
+	// per item.  The stores are plain (write-through L1, merged in L2; the barrier before pass B
+	// orders them), the loads bypass L1 (agent scope: the area is reused tile after tile and L1
+	// may hold the previous tile's lines).  Only what exceeds that too is searched in place by
+	// the lane that found it.
 	unsigned	*const spill = hb.spill + size_t( blockIdx.x ) * hb.spill_cap;
 	const int	qtotal = qcap + hb.spill_cap;
 	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
@@ -407,7 +409,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( slot_ < qcap ) \
 					queue[ slot_ ] = ( item ) | slot_bits; \
 				else if( slot_ < qtotal ) \
-					__hip_atomic_store( spill + ( slot_ - qcap ), ( item ) | slot_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); \
+					spill[ slot_ - qcap ] = ( item ) | slot_bits; \
 				else if constexpr( LEAN ){ \
 					rmd_lean_t	st_; \
 					int	k_ = rmd_lean_begin( P, lr, st_, szero_, slen, r0_, cnt_ ); \
@@ -935,14 +937,23 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 			density *= std::min( 1.0, pl * ( dp.lit_hi - dp.lit_lo + 1 ) );
 		}
 		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64;	// (static __shared__: 32 bytes)
+		// What the LDS queue cannot hold spills to HBM at 4 bytes per item, so LDS goes to the tile
+		// first and the queue gets what is left, up to the expected number of items (trna.descr:
+		// queue 1024 / T 9984 3.99 ms, 512 / 11008 3.94, 256 / 11520 3.91 -- the last spills a
+		// third of its items for that 1 %: the queue starts at 512).  A tile should still not
+		// produce more than half the spill area on average.
+		const int	q_min = 512;
 		sc->tile_t = 2048;
 		for( int t = 16384; t >= 2048; t -= 256 )
-			if( search_lds_bytes( sc->prog_bytes, dp, t, true, sc->qcap ) <= budget && density * t * 1.1 <= sc->qcap ){
+			if( search_lds_bytes( sc->prog_bytes, dp, t, true, q_min ) <= budget &&
+				density * t * 1.1 <= q_min + std::max( sc->spill_cap, 2 * 512 ) / 2 ){
 				sc->tile_t = t;
 				break;
 			}
-		if( density * sc->tile_t * 1.1 > sc->qcap )	// dense survivors: a longer queue rather than the in-place fallback
-			sc->qcap = int( std::min( 8192.0, std::ceil( density * sc->tile_t * 1.2 / 256 ) * 256 ) );
+		sc->qcap = q_min;
+		const int	q_want = int( std::min( 8192.0, std::ceil( density * sc->tile_t * 1.2 / 256 ) * 256 ) );
+		while( sc->qcap + 256 <= q_want && search_lds_bytes( sc->prog_bytes, dp, sc->tile_t, true, sc->qcap + 256 ) <= budget )
+			sc->qcap += 256;
 	}
 	if( !sc->dprog.lean_ok ){
 		// general instance: LDS is not what limits it (frames live in scratch), so larger
@@ -1030,9 +1041,9 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 			grouped = force[ 0 ] == '1';
 		if( grouped && sc->dprog.lean_ok ){
 			const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64 - SHORT_GROUP * 32;
-			const double	per_pos = double( sc->qcap ) / sc->tile_t;
-			for( int t = 1024; t >= 256; t -= 256 ){
-				int	q = std::max( 256, int( std::ceil( per_pos * t * SHORT_GROUP / 256 ) ) * 256 );
+			// (tiles of 1024 positions measured slower than of 768 where both fit: mp.ends 1.56 / 1.40 ms)
+			for( int t = 768; t >= 256; t -= 256 ){
+				int	q = 256;	// LDS goes to the slots; what a group queues beyond this spills
 				if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )	// tests: force the overflow path
 					q = std::max( 64, atoi( qq ) );
 				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true, q, SHORT_GROUP ) <= budget ){
