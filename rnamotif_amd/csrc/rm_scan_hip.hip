@@ -956,11 +956,17 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 			sc->qcap += 256;
 	}
 	if( !sc->dprog.lean_ok ){
-		// general instance: LDS is not what limits it (frames live in scratch), so larger
-		// tiles and a queue that holds their items (pk1 41.9 -> 32 ms, qu+tr 94 -> 87 ms at
-		// 4096; at 8192 a 1024-entry queue overflows into the in-place search: 175 ms)
-		sc->tile_t = 4096;
-		sc->qcap = 4096;
+		// general instance: LDS is not what limits it (frames live in scratch), so larger tiles
+		// (pk1 41.9 -> 32 ms, qu+tr 94 -> 87 ms at 4096 with a queue that held all their items;
+		// with the queue's spill area a 1024-entry queue and tiles of 8192 positions: pk1 27.8,
+		// qu+tr 74 ms; 12288: 30.0 / 81) as long as six workgroups share a CU's LDS
+		sc->qcap = 1024;
+		sc->tile_t = 8192;
+		if( sc->spill_cap < 4096 ||
+			search_lds_bytes( sc->prog_bytes, sc->dprog, sc->tile_t, false, sc->qcap ) > ( 160 * 1024 ) / GENERAL_WAVES_PER_SIMD - 64 ){
+			sc->tile_t = 4096;
+			sc->qcap = 4096;
+		}
 	}
 	if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )
 		if( atoi( qq ) >= 64 && atoi( qq ) <= 16384 )
