@@ -185,7 +185,7 @@ struct TailAccel {
 #ifndef SHORT_GROUP
 #define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
 #endif
-#define SHORT_ENTRY_MEAN	3000
+#define SHORT_ENTRY_MEAN	4000
 #define SPILL_ITEMS		8192	// queue items per workgroup that may overflow into HBM (32 KB each, 64 MB in all)	// ... which are those whose entries average less than this
 // G: tiles per workgroup pass.  G == 1: one tile, all lanes on it.  G > 1 (databases of short
 // entries, lean descriptors only): a group of G small tiles, each in its own LDS slot and
