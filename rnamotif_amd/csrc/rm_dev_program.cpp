@@ -147,8 +147,12 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			for( int k = e.index + 1; k < e.mates[ 0 ]; k++ )
 				d->q_iminl += p->elems[ k ].minlen;
 			d->q_sminl = 0;
-			for( int k = e.mates[ 0 ] + 1; k <= e.scopes[ e.n_scopes - 1 ]; k++ )
+			int64_t	smax = 0;
+			for( int k = e.mates[ 0 ] + 1; k <= e.scopes[ e.n_scopes - 1 ]; k++ ){
 				d->q_sminl += p->elems[ k ].minlen;
+				smax += p->elems[ k ].maxlen;
+			}
+			d->q_smaxl = smax < 30000 ? int32_t( smax ) : -1;
 		}
 		// every strand of a helix carries the group's rules (match_4plex reads them from q2)
 		bool	helix = e.type != RMA_T_SS && e.type != RMA_T_CTX;
@@ -248,6 +252,66 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		if( !( e.type == RMA_T_SS || ( e.type == RMA_T_H5 && e.proper ) ) )
 			out->lean_ok = 0;
 	}
+	// improper helices: the sums find_pknot5/find_pknot3 take over ranges of the knot (rmd_pk_t)
+	int	n_pks = 0;
+	for( int d = 0; d < p->n_elems; d++ )
+		out->elems[ d ].pk = -1;
+	for( int s = 0; s < p->n_searches; s++ ){
+		const rma_elem_t	&e = p->elems[ p->searches[ s ] ];
+		if( e.type != RMA_T_H5 || e.proper )
+			continue;
+		if( n_pks == RMD_MAX_PK )
+			FAIL( "more than %d pseudoknot helices", RMD_MAX_PK );
+		rmd_pk_t	&pk = out->pks[ n_pks ];
+		memset( &pk, 0, sizeof( pk ) );
+		const int	d = e.index, d3 = e.mates[ 0 ], d0 = e.scopes[ 0 ], dn = e.scopes[ e.n_scopes - 1 ];
+		// the helix a strand of the knot belongs to, as the search level of its 5' strand
+		auto level_of = [&]( int el ) -> int {
+			const rma_elem_t	&x = p->elems[ el ];
+			return x.type == RMA_T_H5 ? x.searchno : p->elems[ x.mates[ 0 ] ].searchno;
+		};
+		for( int k = 0; k < 8; k++ )
+			pk.lvl[ k ] = k < e.n_scopes ? int8_t( level_of( e.scopes[ k ] ) ) : int8_t( -1 );
+		pk.hlx2 = d == e.scopes[ 1 ];
+		const int	d3_h1 = p->elems[ e.scopes[ 0 ] ].mates[ 0 ];
+		const int	lo[ RMD_PK_N ] = { d0, d, d + 1, d3 + 1, d + 1, d3_h1 + 1 };
+		const int	hi[ RMD_PK_N ] = { d - 1, dn, d3 - 1, dn, d3_h1 - 1, d3 - 1 };
+		for( int q = 0; q < RMD_PK_N; q++ ){
+			if( ( q == RMD_PK_IL || q == RMD_PK_IR ) && !pk.hlx2 )
+				continue;
+			int64_t	mn = 0, mx = 0;
+			for( int el = lo[ q ]; el <= hi[ q ]; el++ ){
+				int	sc = -1;
+				for( int k = 0; k < e.n_scopes; k++ )
+					if( e.scopes[ k ] == el )
+						sc = k;
+				if( sc >= 0 && level_of( el ) < e.searchno ){
+					pk.mask[ q ] |= uint8_t( 1u << sc );
+					continue;
+				}
+				mn += p->elems[ el ].minlen;
+				mx += p->elems[ el ].maxlen;
+			}
+			pk.bmin[ q ] = int32_t( std::min<int64_t>( mn, 1000000000 ) );
+			pk.bmax[ q ] = int32_t( std::min<int64_t>( mx, 1000000000 ) );
+		}
+		// upd_pksearches(), find_motif.c:667-701
+		pk.w_osd5 = pk.w_zero5 = pk.w_osd3 = pk.w_zero3 = -1;
+		auto inner_level = [&]( int el ) -> int8_t {
+			const int	in = p->elems[ el ].inner;
+			return in >= 0 ? int8_t( p->elems[ in ].searchno ) : int8_t( -1 );
+		};
+		if( e.scope > 0 )
+			pk.w_osd5 = inner_level( e.scopes[ e.scope - 1 ] );
+		pk.w_zero5 = inner_level( d );
+		const rma_elem_t	&e3 = p->elems[ d3 ];
+		if( e3.scope > 0 )
+			pk.w_osd3 = inner_level( e3.scopes[ e3.scope - 1 ] );
+		if( e3.scope < e3.n_scopes - 1 )
+			pk.w_zero3 = inner_level( d3 );
+		out->elems[ d ].pk = int8_t( n_pks++ );
+	}
+	out->n_pks = n_pks;
 	for( int d = 0; d < p->n_elems; d++ ){
 		out->elems[ d ].rem_min = 0;
 		out->elems[ d ].rem_max = -1;
@@ -408,6 +472,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 	out->off_regexes = int32_t( offsetof( rmd_program_t, regexes ) );
 	out->off_rules = int32_t( offsetof( rmd_program_t, rules ) );
 	out->off_pairsets = int32_t( offsetof( rmd_program_t, pairsets ) );
+	out->off_pks = int32_t( offsetof( rmd_program_t, pks ) );
 	out->image_bytes = int32_t( sizeof( rmd_program_t ) );
 	return 0;
 #undef FAIL
@@ -434,6 +499,10 @@ size_t rmd_make_image( const rmd_program_t *full, void *img )
 	hdr->off_pairsets = int32_t( n );
 	memcpy( out + n, full->pairsets, size_t( full->n_pairsets ) * sizeof( rmd_pairset_t ) );
 	n += size_t( full->n_pairsets ) * sizeof( rmd_pairset_t );
+	n = align( n, alignof( rmd_pk_t ) );
+	hdr->off_pks = int32_t( n );
+	memcpy( out + n, full->pks, size_t( full->n_pks ) * sizeof( rmd_pk_t ) );
+	n += size_t( full->n_pks ) * sizeof( rmd_pk_t );
 	n = align( n, 16 );
 	hdr->image_bytes = int32_t( n );
 	return n;

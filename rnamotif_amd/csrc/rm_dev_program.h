@@ -21,6 +21,7 @@
 #define RMD_MAX_RULES	16	// helix groups with their own mispair / pairfrac rule tables
 #define RMD_MAX_SITES	8
 #define RMD_MAX_EFN	8
+#define RMD_MAX_PK	16	// improper (pseudoknot) helices per descriptor
 
 // position automaton of one seq= expression: state i (bit i) accepts one base
 struct rmd_regex_t {
@@ -56,6 +57,7 @@ struct rmd_elem_t {
 	int8_t	quick;			// level searched with match_wchlx at (zero, sdollar): proper h5, q1
 	int32_t	q_iminl;		// interior minimum of that match (find_motif.c:423,884)
 	int32_t	q_sminl;		// first pseudoknot helix: least length after its 3' strand (:561)
+	int32_t	q_smaxl;		// ... and the most (:562), -1: not bounded
 	int32_t	minlen, maxlen, minglen, maxglen, minilen, maxilen;
 	int32_t	mismatch;
 	int32_t	mplim;			// match_wchlx/match_phlx mispair limit
@@ -65,8 +67,31 @@ struct rmd_elem_t {
 	int16_t	rem_max;		// most (closed chains only), -1: unknown / open chain
 	int8_t	tail_s;			// helix: level of the last group of its interior if that is a
 					// proper helix (its 3' end is pinned to the interior's end), else -1
-	int8_t	pad_[ 3 ];
+	int8_t	pk;			// improper helix: index into pks[], else -1
+	int8_t	pad_[ 2 ];
 	int16_t	tail_pre_min, tail_pre_max;	// total length of the interior groups before it (-1: unbounded)
+};
+
+// Improper (pseudoknot) helix: what find_pknot5()/find_pknot3() compute with find_minlen()/
+// find_maxlen() (find_motif.c:495-665) over ranges of the knot's elements.  When helix i of a
+// knot is searched, exactly the strands of its helices 0..i-1 are matched (the knot's helices
+// head consecutive search levels, their interiors come later: find_search_order, compile.c:
+// 3163-3190), so every such sum is a constant plus the current lengths of some earlier helices.
+enum { RMD_PK_P = 0,	// scopes[0] .. d-1
+	RMD_PK_R,	// d .. scopes[n-1]
+	RMD_PK_I,	// d+1 .. d3-1
+	RMD_PK_S,	// d3+1 .. scopes[n-1]
+	RMD_PK_IL,	// second helix: d+1 .. (3' strand of the first helix)-1
+	RMD_PK_IR,	// second helix: (3' strand of the first helix)+1 .. d3-1
+	RMD_PK_N };
+struct rmd_pk_t {
+	int32_t	bmin[ RMD_PK_N ], bmax[ RMD_PK_N ];	// sum over the elements of the range that are not matched yet
+	uint8_t	mask[ RMD_PK_N ];	// bit s: strand scopes[s] lies in the range and is matched (earlier helix)
+	int8_t	lvl[ 8 ];		// search level of the helix that strand scopes[s] belongs to
+	int8_t	hlx2;			// this is the knot's second helix (find_pknot3 :571)
+	// upd_pksearches(), :667: levels whose window end becomes s5-1, start s5+hl, end s3-hl, start s3+1 (-1: none)
+	int8_t	w_osd5, w_zero5, w_osd3, w_zero3;
+	int8_t	pad_[ 3 ];
 };
 
 // length dependent helix rules, shared by the strands of one helix
@@ -102,8 +127,8 @@ struct rmd_program_t {
 	// what the descriptor uses: the members up to elems[ n_elems ], then the used regexes,
 	// rules and pair sets back to back (rmd_make_image()).  In this full struct the offsets
 	// point at the arrays below.
-	int32_t	n_regexes, n_rules, n_pairsets;
-	int32_t	off_regexes, off_rules, off_pairsets;
+	int32_t	n_regexes, n_rules, n_pairsets, n_pks;
+	int32_t	off_regexes, off_rules, off_pairsets, off_pks;
 	int32_t	image_bytes;
 	int8_t	searches[ RMD_MAX_ELEMS ];
 	rmd_elem_t	lctx, rctx;
@@ -113,6 +138,7 @@ struct rmd_program_t {
 	rmd_regex_t	regexes[ RMD_MAX_RE ];
 	rmd_rule_t	rules[ RMD_MAX_RULES ];
 	rmd_pairset_t	pairsets[ RMD_MAX_PS ];
+	rmd_pk_t	pks[ RMD_MAX_PK ];
 };
 
 #ifndef RMD_HD
@@ -129,6 +155,11 @@ RMD_HD const rmd_rule_t *rmd_rules( const rmd_program_t *P )
 RMD_HD const rmd_pairset_t *rmd_pairsets( const rmd_program_t *P )
 {
 	return reinterpret_cast<const rmd_pairset_t *>( reinterpret_cast<const char *>( P ) + P->off_pairsets );
+}
+
+RMD_HD const rmd_pk_t *rmd_pks( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rmd_pk_t *>( reinterpret_cast<const char *>( P ) + P->off_pks );
 }
 
 // Build the device form; returns 0 or -1 with a message (descriptor outside

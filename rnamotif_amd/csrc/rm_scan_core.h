@@ -39,22 +39,15 @@ static long long	rmd_stat[ 16 ];
 #define RMD_COUNT( i )	( ( void )0 )
 #endif
 
-struct rmd_frame_t {
-	int32_t	sd, sd_lo, o_sd;	// find_motif's sdollar loop: next value, last value, saved s_dollar
-	int32_t	ph;			// generator phase
-	int32_t	a, b, c, d, e, f;	// per-type loop variables
-	int32_t	i_minl;			// pknot: interior minimum for this (s5)
-	uint64_t	cand;		// helix lengths that match_wchlx accepted (bit hl)
-	uint64_t	mis;		// bit i: pair i of the helix is a mispair
-};
-
+// What a complete structural match leaves behind (s_matchoff/s_matchlen/s_n_mispairs/
+// s_n_mismatches of every element, rnamot.h:235-238, plus the context spans): rebuilt from the
+// search records only when a candidate reaches the end of the search list, then run through
+// chk_motif / set_context / chk_sites and written out.  The search itself never touches it.
 struct rmd_lane_t {
-	int32_t	zero[ RMD_MAX_ELEMS ], dollar[ RMD_MAX_ELEMS ];	// SEARCH_T s_zero/s_dollar
 	int32_t	moff[ RMD_MAX_ELEMS ], mlen[ RMD_MAX_ELEMS ];	// s_matchoff/s_matchlen
 	int16_t	mpr[ RMD_MAX_ELEMS ], mm[ RMD_MAX_ELEMS ];	// s_n_mispairs/s_n_mismatches
-	rmd_frame_t	fr[ RMD_MAX_ELEMS ];
 	int32_t	l_off, l_len, r_off, r_len, l_mm, r_mm;
-	int32_t	slen, szero, hi0;
+	int32_t	slen, szero;
 	int32_t	rank, order;
 };
 
@@ -253,19 +246,9 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const rmd_seq_t &sq,
 	return c != 0;
 }
 
-RMD_FN int rmd_match_wchlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis )
-{
-	int	mm5 = L->mm[ d5 ], mm3 = L->mm[ d3 ];
-	int	rv = rmd_match_wchlx_mm( P, sq, d5, d3, s5, s3, s3lim, cand, mis, &mm5, &mm3 );
-	L->mm[ d5 ] = int16_t( mm5 );
-	L->mm[ d3 ] = int16_t( mm3 );
-	return rv;
-}
-
-// match_phlx(), find_motif.c:1114
-RMD_COLD int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int d5, int d3, int s5, int s3, int s5hi, int s5lo, int *hlen, int *n_mpr )
+// match_phlx(), find_motif.c:1114.  mm5/mm3: s_n_mismatches of the two strands, in and out.
+RMD_COLD int rmd_match_phlx( const rmd_program_t *P, const rmd_seq_t &sq,
+	int d5, int d3, int s5, int s3, int s5hi, int s5lo, int *hlen, int *n_mpr, int *mm5, int *mm3 )
 {
 	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
 	int	b3 = rmd_code( sq, s3 );
@@ -297,21 +280,10 @@ RMD_COLD int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_se
 			return 0;
 		if( stp.pfrac && mpr > rmd_rules( P )[ stp.rule ].pf_maxmpr[ hl ] )
 			return 0;
-		int	mm;
-		if( stp.re >= 0 ){
-			mm = L->mm[ d5 ];
-			int	ok = rmd_chk_seq( P, stp, sq, s5, hl, &mm );
-			L->mm[ d5 ] = int16_t( mm );
-			if( !ok )
-				return 0;
-		}
-		if( stp3.re >= 0 ){
-			mm = L->mm[ d3 ];
-			int	ok = rmd_chk_seq( P, stp3, sq, s3 - hl + 1, hl, &mm );
-			L->mm[ d3 ] = int16_t( mm );
-			if( !ok )
-				return 0;
-		}
+		if( stp.re >= 0 && !rmd_chk_seq( P, stp, sq, s5, hl, mm5 ) )
+			return 0;
+		if( stp3.re >= 0 && !rmd_chk_seq( P, stp3, sq, s3 - hl + 1, hl, mm3 ) )
+			return 0;
 		*hlen = hl;
 		*n_mpr = mpr;
 		return 1;
@@ -319,9 +291,9 @@ RMD_COLD int rmd_match_phlx( const rmd_program_t *P, rmd_lane_t *L, const rmd_se
 	return 0;
 }
 
-// match_triplex(), find_motif.c:1183
-RMD_COLD int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int d, int d1, int s1, int s2, int s3, int tlen, int *n_mpr )
+// match_triplex(), find_motif.c:1183.  mm1: s_n_mismatches of the middle strand.
+RMD_COLD int rmd_match_triplex( const rmd_program_t *P, const rmd_seq_t &sq,
+	int d, int d1, int s1, int s2, int s3, int tlen, int *n_mpr, int *mm1 )
 {
 	const rmd_elem_t	&stp = P->elems[ d ], &stp1 = P->elems[ d1 ];
 	int	mplim = rmd_rules( P )[ stp.rule ].tq_mplim[ tlen ], mpr, l_pr;
@@ -343,20 +315,15 @@ RMD_COLD int rmd_match_triplex( const rmd_program_t *P, rmd_lane_t *L, const rmd
 	}
 	if( !l_pr && ( stp.ends & RMA_3PAIRED ) )
 		return 0;
-	if( stp1.re >= 0 ){
-		int	mm = L->mm[ d1 ];
-		int	ok = rmd_chk_seq( P, stp1, sq, s2 - tlen + 1, tlen, &mm );
-		L->mm[ d1 ] = int16_t( mm );
-		if( !ok )
-			return 0;
-	}
+	if( stp1.re >= 0 && !rmd_chk_seq( P, stp1, sq, s2 - tlen + 1, tlen, mm1 ) )
+		return 0;
 	*n_mpr = mpr;
 	return 1;
 }
 
-// match_4plex(), find_motif.c:1234
-RMD_COLD int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int d1, int d2, int s1, int s2, int s3, int s4, int qlen, int *n_mpr )
+// match_4plex(), find_motif.c:1234.  mm1/mm2: s_n_mismatches of the two inner strands.
+RMD_COLD int rmd_match_4plex( const rmd_program_t *P, const rmd_seq_t &sq,
+	int d1, int d2, int s1, int s2, int s3, int s4, int qlen, int *n_mpr, int *mm1, int *mm2 )
 {
 	const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
 	int	mplim = rmd_rules( P )[ stp1.rule ].tq_mplim[ qlen ], mpr, l_pr;
@@ -378,21 +345,10 @@ RMD_COLD int rmd_match_4plex( const rmd_program_t *P, rmd_lane_t *L, const rmd_s
 	}
 	if( !l_pr && ( stp1.ends & RMA_3PAIRED ) )
 		return 0;
-	int	mm;
-	if( stp1.re >= 0 ){
-		mm = L->mm[ d1 ];
-		int	ok = rmd_chk_seq( P, stp1, sq, s2, qlen, &mm );
-		L->mm[ d1 ] = int16_t( mm );
-		if( !ok )
-			return 0;
-	}
-	if( stp2.re >= 0 ){
-		mm = L->mm[ d2 ];
-		int	ok = rmd_chk_seq( P, stp2, sq, s3 - qlen + 1, qlen, &mm );
-		L->mm[ d2 ] = int16_t( mm );
-		if( !ok )
-			return 0;
-	}
+	if( stp1.re >= 0 && !rmd_chk_seq( P, stp1, sq, s2, qlen, mm1 ) )
+		return 0;
+	if( stp2.re >= 0 && !rmd_chk_seq( P, stp2, sq, s3 - qlen + 1, qlen, mm2 ) )
+		return 0;
 	*n_mpr = mpr;
 	return 1;
 }
@@ -426,6 +382,7 @@ RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const
 		hl++;
 	}
 }
+
 
 // ---------------------------------------------------------------- terminal checks
 // fm_window[] lookup (find_motif.c:1333-1385 marks): type of the element that
@@ -567,24 +524,7 @@ RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const r
 	return 1;
 }
 
-// ---------------------------------------------------------------- level generators
-RMD_FN int rmd_find_minlen( const rmd_program_t *P, const rmd_lane_t *L, int fd, int ld )	// :642
-{
-	int	v = 0;
-	for( int d = fd; d <= ld; d++ )
-		v += L->mlen[ d ] != RMD_UNDEF ? L->mlen[ d ] : P->elems[ d ].minlen;
-	return v;
-}
-RMD_FN int rmd_find_maxlen( const rmd_program_t *P, const rmd_lane_t *L, int fd, int ld )	// :655
-{
-	int	v = 0;
-	for( int d = fd; d <= ld; d++ )
-		v += L->mlen[ d ] != RMD_UNDEF ? L->mlen[ d ] : P->elems[ d ].maxlen;
-	return v;
-}
-
-RMD_FN void rmd_unmark( rmd_lane_t *L, int d ) { L->moff[ d ] = L->mlen[ d ] = RMD_UNDEF; }
-RMD_FN void rmd_mark( rmd_lane_t *L, int d, int off, int len ) { L->moff[ d ] = off; L->mlen[ d ] = len; }
+// ---------------------------------------------------------------- helpers of the level generators
 RMD_FN int rmd_imin( int a, int b ) { return a < b ? a : b; }
 RMD_FN int rmd_imax( int a, int b ) { return a > b ? a : b; }
 
@@ -594,23 +534,6 @@ RMD_FN int rmd_s3lim( int szero, int sdollar, int i_minl, int h_maxl )	// find_m
 	v = ( v - i_minl ) / 2;
 	v = rmd_imin( v, h_maxl );
 	return sdollar - v + 1;
-}
-
-// find_motif(), :245: prepare the loop over the level's end position
-RMD_FN void rmd_enter( const rmd_program_t *P, rmd_lane_t *L, int k )
-{
-	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
-	rmd_frame_t	&f = L->fr[ k ];
-	f.o_sd = L->dollar[ k ];
-	if( stp.loop ){
-		int	hi = L->dollar[ k ];
-		if( stp.maxglen != RMA_UNBOUNDED && L->zero[ k ] + stp.maxglen - 1 < hi )
-			hi = L->zero[ k ] + stp.maxglen - 1;
-		f.sd = hi;
-		f.sd_lo = L->zero[ k ] + stp.minglen - 1;
-	}else
-		f.sd = f.sd_lo = L->dollar[ k ];
-	f.ph = 0;
 }
 
 // phlx/triplex end bounds, find_motif.c:730-739, :801-810
@@ -624,393 +547,6 @@ RMD_FN void rmd_phlx_bounds( int szero, int slen, int h_minl, int h_maxl, int i_
 		lo++;
 	lo = rmd_imin( lo / 2, h_maxl );
 	*s5lo = szero + lo - 1;
-}
-
-// upd_pksearches(), :667
-RMD_FN void rmd_upd_pksearches( const rmd_program_t *P, rmd_lane_t *L, int d, int h5, int h3, int hlen )
-{
-	const rmd_elem_t	&stp = P->elems[ d ];
-	int	i;
-	if( stp.scope > 0 ){
-		i = P->elems[ stp.scopes[ stp.scope - 1 ] ].inner_s;
-		if( i >= 0 )
-			L->dollar[ i ] = h5 - 1;
-	}
-	if( stp.inner_s >= 0 )
-		L->zero[ stp.inner_s ] = h5 + hlen;
-	const rmd_elem_t	&stp3 = P->elems[ stp.mates[ 0 ] ];
-	i = P->elems[ stp3.scopes[ stp3.scope - 1 ] ].inner_s;
-	if( i >= 0 )
-		L->dollar[ i ] = h3 - hlen;
-	if( stp3.scope < stp3.n_scopes - 1 && stp3.inner_s >= 0 )
-		L->zero[ stp3.inner_s ] = h3 + 1;
-}
-
-// Advance level k to its next alternative.  Returns 1 with the alternative
-// applied (elements marked, later windows set), 0 when the level is exhausted.
-RMD_COLD int rmd_next_general( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
-{
-	const int	d = P->searches[ k ];
-	const rmd_elem_t	&stp = P->elems[ d ];
-	rmd_frame_t	&f = L->fr[ k ];
-
-	RMD_COUNT( 0 );
-	for( ; ; ){
-		RMD_COUNT( 1 );
-		if( f.ph == 0 ){
-			RMD_COUNT( 2 + ( stp.type == RMA_T_SS ? 0 : 1 ) );
-			// next end position of find_motif's loop
-			if( f.sd < f.sd_lo ){
-				L->dollar[ k ] = f.o_sd;
-				return 0;
-			}
-			if( stp.quick ){
-				// end positions whose first base pairs cannot start this helix are
-				// skipped without touching the search state (they have no effect
-				// that outlives the iteration, find_motif.c:273-280,1010-1021)
-				const int	z = L->zero[ k ];
-				while( f.sd >= f.sd_lo &&
-					!rmd_quick_wchlx( P, stp, sq, z, f.sd, rmd_s3lim( z, f.sd, stp.q_iminl, stp.maxlen ) ) )
-					f.sd--;
-				if( f.sd < f.sd_lo ){
-					L->dollar[ k ] = f.o_sd;
-					return 0;
-				}
-			}
-			if( stp.loop ){
-				if( k == 0 ){
-					L->rank = L->hi0 - f.sd;
-					L->order = 0;
-				}
-				L->dollar[ k ] = f.sd;
-				if( stp.next_s >= 0 ){
-					L->zero[ stp.next_s ] = f.sd + 1;
-					L->dollar[ stp.next_s ] = f.o_sd;
-				}
-			}
-			f.sd--;
-			const int	szero = L->zero[ k ], sdollar = L->dollar[ k ], slen = sdollar - szero + 1;
-			switch( stp.type ){
-			case RMA_T_SS : {			// find_ss :332
-				L->mm[ d ] = 0;
-				L->mpr[ d ] = 0;
-				if( slen < stp.minlen || slen > stp.maxlen )
-					continue;
-				if( stp.re >= 0 ){
-					int	mm = 0;
-					int	ok = rmd_chk_seq( P, stp, sq, szero, slen, &mm );
-					L->mm[ d ] = int16_t( mm );
-					if( !ok )
-						continue;
-				}
-				rmd_mark( L, d, szero, slen );
-				f.ph = 1;
-				return 1;
-			}
-			case RMA_T_H5 :
-				if( stp.proper ){		// find_wchlx :400
-					int	d3 = stp.mates[ 0 ];
-					L->mm[ d ] = L->mpr[ d ] = 0;
-					L->mm[ d3 ] = L->mpr[ d3 ] = 0;
-					int	s3lim = rmd_s3lim( szero, sdollar, stp.minilen, stp.maxlen );
-					if( !rmd_match_wchlx( P, L, sq, d, d3, szero, sdollar, s3lim, &f.cand, &f.mis ) )
-						continue;
-					f.ph = 1;
-				}else{				// find_pknot :465, find_pknot5 :495
-					if( stp.scope == 0 ){
-						for( int s = 1; s < stp.n_scopes; s++ ){
-							int	d1 = stp.scopes[ s ];
-							if( P->elems[ d1 ].type == RMA_T_H5 ){
-								int	s1 = P->elems[ d1 ].searchno;
-								rmd_unmark( L, d1 );
-								L->zero[ s1 ] = szero;
-								L->dollar[ s1 ] = sdollar;
-							}
-						}
-					}
-					int	d0 = stp.scopes[ 0 ], dn = stp.scopes[ stp.n_scopes - 1 ];
-					int	p_minl = rmd_find_minlen( P, L, d0, d - 1 ), p_maxl = rmd_find_maxlen( P, L, d0, d - 1 );
-					int	r_minl = rmd_find_minlen( P, L, d, dn ), r_maxl = rmd_find_maxlen( P, L, d, dn );
-					if( p_maxl + r_maxl < slen )
-						continue;
-					f.a = szero + p_minl;					// s5
-					f.b = szero + rmd_imin( p_maxl, slen - r_minl );	// l_s5
-					f.ph = 1;
-				}
-				break;
-			case RMA_T_P5 : {			// find_phlx :703
-				int	d3 = stp.mates[ 0 ];
-				L->mm[ d ] = L->mpr[ d ] = 0;
-				L->mm[ d3 ] = L->mpr[ d3 ] = 0;
-				int	s5hi, s5lo, hlen, n_mpr;
-				rmd_phlx_bounds( szero, slen, stp.minlen, stp.maxlen, stp.minilen, stp.maxilen, &s5hi, &s5lo );
-				if( !rmd_match_phlx( P, L, sq, d, d3, szero, sdollar, s5hi, s5lo, &hlen, &n_mpr ) )
-					continue;
-				if( sdollar - szero - 2 * hlen + 1 > stp.maxilen )
-					continue;
-				L->mpr[ d ] = L->mpr[ d3 ] = int16_t( n_mpr );
-				rmd_mark( L, d, szero, hlen );
-				rmd_mark( L, d3, sdollar - hlen + 1, hlen );
-				L->zero[ stp.inner_s ] = szero + hlen;
-				L->dollar[ stp.inner_s ] = sdollar - hlen;
-				f.ph = 1;
-				return 1;
-			}
-			case RMA_T_T1 : {			// find_triplex :763
-				int	d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
-				const rmd_elem_t	&stp1 = P->elems[ d1 ];
-				L->mm[ d ] = L->mpr[ d ] = 0;
-				L->mm[ d1 ] = L->mpr[ d1 ] = 0;
-				L->mm[ d2 ] = L->mpr[ d2 ] = 0;
-				int	s5hi, s5lo, hlen, n_mpr;
-				rmd_phlx_bounds( szero, slen, stp.minlen, stp.maxlen, stp.minilen + stp1.minilen,
-					stp.maxilen + stp.minlen + stp1.maxilen, &s5hi, &s5lo );
-				if( !rmd_match_phlx( P, L, sq, d, d2, szero, sdollar, s5hi, s5lo, &hlen, &n_mpr ) )
-					continue;
-				if( sdollar - szero - 2 * hlen + 1 > stp.maxilen + stp1.maxilen + hlen )
-					continue;
-				rmd_mark( L, d, szero, hlen );
-				rmd_mark( L, d2, sdollar - hlen + 1, hlen );
-				f.c = hlen;
-				f.a = sdollar - stp1.minilen - hlen;			// s
-				f.b = szero + 2 * hlen + stp.minilen - 1;		// last s
-				f.ph = 1;
-				break;
-			}
-			case RMA_T_Q1 : {			// find_4plex :851
-				int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
-				L->mm[ d ] = L->mpr[ d ] = 0;
-				L->mm[ d1 ] = L->mpr[ d1 ] = 0;
-				L->mm[ d2 ] = L->mpr[ d2 ] = 0;
-				L->mm[ d3 ] = L->mpr[ d3 ] = 0;
-				int	i_minl = stp.minilen + P->elems[ d1 ].minilen + P->elems[ d2 ].minilen + 2 * stp.minlen;
-				int	s3lim = rmd_s3lim( szero, sdollar, i_minl, stp.maxlen );
-				if( !rmd_match_wchlx( P, L, sq, d, d3, szero, sdollar, s3lim, &f.cand, &f.mis ) )
-					continue;
-				f.ph = 1;
-				break;
-			}
-			default :
-				continue;
-			}
-			continue;
-		}
-
-		// ph != 0: produce the next alternative at the current end position
-		const int	szero = L->zero[ k ], sdollar = L->dollar[ k ];
-		switch( stp.type ){
-		case RMA_T_SS :
-			rmd_unmark( L, d );
-			f.ph = 0;
-			continue;
-		case RMA_T_H5 :
-			if( stp.proper ){
-				int	d3 = stp.mates[ 0 ];
-				rmd_unmark( L, d );
-				rmd_unmark( L, d3 );
-				if( f.cand == 0 ){
-					f.ph = 0;
-					continue;
-				}
-				int	hl = rmd_ctz64( f.cand );
-				f.cand &= f.cand - 1;
-				if( sdollar - szero - 2 * hl + 1 > stp.maxilen )
-					continue;
-				int	mpr = rmd_popc64( f.mis & ( ( 1ull << hl ) - 1 ) );
-				L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
-				rmd_mark( L, d, szero, hl );
-				rmd_mark( L, d3, sdollar - hl + 1, hl );
-				L->zero[ stp.inner_s ] = szero + hl;
-				L->dollar[ stp.inner_s ] = sdollar - hl;
-				return 1;
-			}else{
-				int	d3 = stp.mates[ 0 ];
-				int	dn = stp.scopes[ stp.n_scopes - 1 ];
-				if( f.ph == 3 ){		// next helix length at (s5,s3), find_pknot3 :607
-					rmd_unmark( L, d );
-					rmd_unmark( L, d3 );
-					const int	s5 = f.e, s3 = f.f;
-					if( f.cand == 0 ){
-						f.ph = 2;
-						continue;
-					}
-					int	hl = rmd_ctz64( f.cand );
-					f.cand &= f.cand - 1;
-					if( ( s3 - s5 + 1 ) - 2 * hl < f.i_minl ){
-						f.ph = 2;	// break: longer helices only get worse
-						continue;
-					}
-					if( d == stp.scopes[ 1 ] ){	// hlx == 2, :571-627
-						int	d3_h1 = P->elems[ stp.scopes[ 0 ] ].mates[ 0 ];
-						int	iL_last = L->moff[ d3_h1 ] - 1, iR_last = L->moff[ d3_h1 ] + L->mlen[ d3_h1 ];
-						int	iL_minl = 0, iL_maxl = 0, iR_minl = 0, iR_maxl = 0;
-						if( d + 1 <= d3_h1 - 1 ){
-							iL_minl = rmd_find_minlen( P, L, d + 1, d3_h1 - 1 );
-							iL_maxl = rmd_find_maxlen( P, L, d + 1, d3_h1 - 1 );
-						}
-						if( d3_h1 + 1 <= d3 - 1 ){
-							iR_minl = rmd_find_minlen( P, L, d3_h1 + 1, d3 - 1 );
-							iR_maxl = rmd_find_maxlen( P, L, d3_h1 + 1, d3 - 1 );
-						}
-						int	il = iL_last - ( s5 + hl - 1 ), ir = ( s3 - hl + 1 ) - iR_last;
-						if( il < iL_minl || il > iL_maxl || ir < iR_minl || ir > iR_maxl )
-							continue;
-					}
-					int	mpr = rmd_popc64( f.mis & ( ( 1ull << hl ) - 1 ) );
-					L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
-					rmd_mark( L, d, s5, hl );
-					rmd_mark( L, d3, s3 - hl + 1, hl );
-					rmd_upd_pksearches( P, L, d, s5, s3, hl );
-					return 1;
-				}
-				if( f.ph == 2 ){		// next 3' end, find_pknot3 :600
-					if( f.c < f.d ){
-						f.ph = 1;
-						continue;
-					}
-					// 3' ends whose first pairs cannot start the helix change nothing: skip them
-					while( f.c >= f.d &&
-						!rmd_quick_wchlx( P, stp, sq, f.e, f.c, rmd_s3lim( f.e, f.c, f.i_minl, stp.maxlen ) ) )
-						f.c--;
-					if( f.c < f.d ){
-						f.ph = 1;
-						continue;
-					}
-					const int	s5 = f.e, s3 = f.c--;
-					f.f = s3;
-					int	s3lim = rmd_s3lim( s5, s3, f.i_minl, stp.maxlen );
-					if( rmd_match_wchlx( P, L, sq, d, d3, s5, s3, s3lim, &f.cand, &f.mis ) )
-						f.ph = 3;
-					continue;
-				}
-				// ph == 1: next 5' start, find_pknot5 :523 / find_pknot3 :548-568
-				if( f.a > f.b ){
-					f.ph = 0;
-					continue;
-				}
-				const int	s5 = f.a++;
-				if( !rmd_prefix_ok( P, stp, sq, s5 ) )
-					continue;
-				int	slen3 = sdollar - s5 + 1;
-				int	i_minl = rmd_find_minlen( P, L, d + 1, d3 - 1 );
-				int	g_minl = 2 * stp.minlen + i_minl;
-				int	s_minl = rmd_find_minlen( P, L, d3 + 1, dn ), s_maxl = rmd_find_maxlen( P, L, d3 + 1, dn );
-				if( g_minl + s_minl > slen3 )
-					continue;
-				f.e = s5;
-				f.i_minl = i_minl;
-				f.c = sdollar - s_minl;						// f_s3
-				f.d = sdollar - rmd_imin( slen3 - g_minl, s_maxl );		// l_s3
-				f.ph = 2;
-				continue;
-			}
-		case RMA_T_P5 :
-			rmd_unmark( L, d );
-			rmd_unmark( L, stp.mates[ 0 ] );
-			f.ph = 0;
-			continue;
-		case RMA_T_T1 : {
-			int	d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
-			const rmd_elem_t	&stp1 = P->elems[ d1 ];
-			const int	hlen = f.c;
-			rmd_unmark( L, d1 );
-			int	found = 0;
-			while( f.a >= f.b ){
-				int	s = f.a--;
-				int	n_mpr;
-				if( !rmd_match_triplex( P, L, sq, d, d1, szero, s, sdollar, hlen, &n_mpr ) )
-					continue;
-				if( s - 2 * hlen - szero + 1 > stp.maxilen )
-					continue;
-				if( sdollar - hlen - s > stp1.maxilen )
-					continue;
-				L->mpr[ d ] = L->mpr[ d1 ] = L->mpr[ d2 ] = int16_t( n_mpr );
-				rmd_mark( L, d1, s - hlen + 1, hlen );
-				L->zero[ stp.inner_s ] = szero + hlen;
-				L->dollar[ stp.inner_s ] = s - hlen;
-				L->zero[ stp1.inner_s ] = s + 1;
-				L->dollar[ stp1.inner_s ] = sdollar - hlen;
-				found = 1;
-				break;
-			}
-			if( found )
-				return 1;
-			rmd_unmark( L, d );
-			rmd_unmark( L, d2 );
-			f.ph = 0;
-			continue;
-		}
-		case RMA_T_Q1 : {
-			int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
-			const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
-			if( f.ph == 1 ){		// next outer helix length, find_4plex :893
-				rmd_unmark( L, d );
-				rmd_unmark( L, d3 );
-				if( f.cand == 0 ){
-					f.ph = 0;
-					continue;
-				}
-				int	hl = rmd_ctz64( f.cand );
-				f.cand &= f.cand - 1;
-				rmd_mark( L, d, szero, hl );
-				rmd_mark( L, d3, sdollar - hl + 1, hl );
-				f.c = hl;
-				f.a = szero + hl + stp.minilen;					// s1
-				f.b = sdollar - 3 * hl - stp2.minilen - stp1.minilen;		// s1lim
-				f.d = sdollar - hl - stp2.minilen;				// s2
-				f.ph = 2;
-				continue;
-			}
-			// ph == 2: find_4plex_inner :902, s1 upwards, s2 downwards
-			const int	hl = f.c, s3 = sdollar;
-			rmd_unmark( L, d1 );
-			rmd_unmark( L, d2 );
-			int	found = 0;
-			while( f.a <= f.b ){
-				int	s1 = f.a;
-				int	s2lim = s1 + 2 * hl + stp1.minilen;
-				if( f.d < s2lim ){
-					f.a++;
-					f.d = s3 - hl - stp2.minilen;
-					continue;
-				}
-				int	s2 = f.d--;
-				int	n_mpr;
-				if( !rmd_match_4plex( P, L, sq, d1, d2, szero, s1, s2, s3, hl, &n_mpr ) )
-					continue;
-				if( s1 - szero - hl + 1 > stp.maxilen )
-					continue;
-				if( s2 - s1 - 2 * hl + 1 > stp1.maxilen )
-					continue;
-				if( s3 - s2 - hl + 1 > stp2.maxilen )
-					continue;
-				L->mpr[ d ] = L->mpr[ d1 ] = L->mpr[ d2 ] = L->mpr[ d3 ] = int16_t( n_mpr );
-				rmd_mark( L, d1, s1, hl );
-				rmd_mark( L, d2, s2 - hl + 1, hl );
-				L->zero[ stp.inner_s ] = szero + hl;
-				L->dollar[ stp.inner_s ] = s1 - 1;
-				L->zero[ stp1.inner_s ] = s1 + hl;
-				L->dollar[ stp1.inner_s ] = s2 - hl;
-				L->zero[ stp2.inner_s ] = s2 + 1;
-				L->dollar[ stp2.inner_s ] = s3 - hl;
-				found = 1;
-				break;
-			}
-			if( found )
-				return 1;
-			f.ph = 1;
-			continue;
-		}
-		default :
-			f.ph = 0;
-			continue;
-		}
-	}
-}
-
-RMD_FN int rmd_next( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k )
-{
-	return rmd_next_general( P, L, sq, k );
 }
 
 // Write one candidate (find_ss :373-392 up to the RM_score() call).
@@ -1053,73 +589,6 @@ RMD_FN void rmd_level0_range( const rmd_program_t *P, int szero, int slen, int *
 // r0/cnt select which end positions of the first element are searched: ranks
 // r0 .. r0+cnt-1 counted from the largest; ( 0, RMD_ALL_RANKS ) is the whole position.
 #define RMD_ALL_RANKS	0x7fffffff
-// Start the search of one work item: returns the level to run next (0).
-RMD_FN int rmd_search_begin( const rmd_program_t *P, rmd_lane_t *L, int szero, int slen, int r0, int cnt )
-{
-	RMD_COUNT( 5 );
-	// without pseudoknots every element is written before it is read
-	// (find_minlen/find_maxlen are the only readers of unmatched elements)
-	if( P->need_init ){
-		for( int i = 0; i < P->n_elems; i++ ){
-			L->moff[ i ] = L->mlen[ i ] = RMD_UNDEF;
-			L->mpr[ i ] = L->mm[ i ] = RMD_UNDEF;
-		}
-	}
-	L->l_mm = L->r_mm = RMD_UNDEF;
-	L->l_off = L->l_len = L->r_off = L->r_len = 0;
-	L->slen = slen;
-	L->szero = szero;
-	L->rank = -1;
-	L->order = 0;
-	L->zero[ 0 ] = szero;
-	L->dollar[ 0 ] = rmd_imin( szero + P->w_winsize - 1, slen - 1 );
-	rmd_enter( P, L, 0 );
-	L->hi0 = L->fr[ 0 ].sd;
-	if( r0 > 0 || cnt != RMD_ALL_RANKS ){
-		rmd_frame_t	&f0 = L->fr[ 0 ];
-		int	hi = f0.sd - r0;
-		int	lo = cnt >= f0.sd - f0.sd_lo + 1 ? f0.sd_lo : hi - cnt + 1;
-		f0.sd = hi;
-		if( lo > f0.sd_lo )
-			f0.sd_lo = lo;
-		L->rank = r0 - 1;
-	}
-	return 0;
-}
-
-// One transition of the search at level k; returns the next level, -1 when the
-// item is finished.  Sink::put( P, L, szero ) stores a candidate.
-template< class Sink >
-RMD_FN int rmd_search_step( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq, int k, Sink &sink )
-{
-	if( !rmd_next( P, L, sq, k ) )
-		return k - 1;
-	if( k < P->n_searches - 1 ){
-		rmd_enter( P, L, k + 1 );
-		return k + 1;
-	}
-	// end of the search list: find_ss :362-393
-	if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
-		return k;
-	if( !rmd_set_context( P, L, sq ) )
-		return k;
-	if( !rmd_chk_sites( P, L, sq ) )
-		return k;
-	sink.put( P, L, L->szero );
-	L->order++;
-	return k;
-}
-
-// The search for one start position (one iteration of RM_find_motif's loops,
-// find_motif.c:184-205), restricted to ranks r0 .. r0+cnt-1 of the first element.
-template< class Sink >
-RMD_FN void rmd_search_position( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq,
-	int szero, int slen, int r0, int cnt, Sink &sink )
-{
-	int	k = rmd_search_begin( P, L, szero, slen, r0, cnt );
-	while( k >= 0 )
-		k = rmd_search_step( P, L, sq, k, sink );
-}
 
 // ---------------------------------------------------------------- lean path
 // Descriptors whose search levels are all ss elements and proper Watson-Crick
@@ -1365,4 +834,620 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 		lr.set( stp.inner_s, rmd_lean_open( P, stp.inner_s, r.zero + hl, cur - hl ) );
 		return k + 1;
 	}
+}
+
+// ---------------------------------------------------------------- general path
+// Every element type: ss, proper and improper (pseudoknot) Watson-Crick helices, parallel
+// helices, triplexes, 4-plexes.  What find_motif()/find_1_motif()/find_ss()/find_wchlx()/
+// find_pknot*()/find_phlx()/find_triplex()/find_4plex*() do by recursion
+// (/root/reference/src/find_motif.c:245-973) is done with one 12-byte record per search level,
+// kept in LDS by the kernel: the level's window (written by the levels above it, piecewise
+// for the interiors of a pseudoknot: upd_pksearches :667), the next end position of
+// find_motif's loop, the loop variables of the level's own type and the helix length of the
+// alternative in use.  A level is a resumable generator: rmd_gen_step() advances the deepest
+// level, descends when it yields and pops when it is exhausted.  Candidate sets of a helix
+// (the reference's h3[]/hlen[]/n_mpr[] arrays) are recomputed when a level is resumed; the
+// element table (s_matchoff ...) is rebuilt from the records only for complete matches
+// (rmd_gen_emit).  All positions in a record are relative to the item's start position.
+struct rmd_grec_t {
+	int16_t	zero;		// window start
+	int16_t	osd;		// window end on entry (o_sdollar)
+	int16_t	sd;		// next end position to try; while ph != 0 the one in use is sd + 1
+	int16_t	a;		// pknot: next 5' start (in use: a - 1); triplex: next end of the middle
+				// strand (in use: a + 1); 4-plex: start of the second strand in use
+	int16_t	c;		// pknot: next 3' end (in use: c + 1); 4-plex: next end of the third strand (in use: c + 1)
+	uint8_t	hl;		// helix length of the alternative in use
+	uint8_t	ph;		// generator phase (0: looking for an end position)
+};
+
+struct rmd_gen_t {
+	int32_t	szero, slen;
+	int32_t	hi0, lo0;	// first level: end position of rank 0, lowest end position allowed
+	int32_t	rank, order;
+	int32_t	pretested;	// the item is one end position that already passed the first-pairs test
+};
+
+// find_minlen()/find_maxlen() over range q of improper helix pk, find_motif.c:642-665
+template< class GR >
+RMD_FN void rmd_pk_len( const rmd_pk_t &pk, const GR &gr, int q, int *mn, int *mx )
+{
+	int	a = pk.bmin[ q ], b = pk.bmax[ q ];
+	for( unsigned m = pk.mask[ q ]; m; m &= m - 1 ){
+		const int	hl = gr.hl( pk.lvl[ rmd_ctz64( m ) ] );
+		a += hl;
+		b += hl;
+	}
+	*mn = a;
+	*mx = b;
+}
+
+// rmd_enter(): start the iterator of level k over its window (find_motif :266-272)
+template< class GR >
+RMD_FN void rmd_gen_open( const rmd_program_t *P, GR &gr, int k )
+{
+	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
+	rmd_grec_t	r = gr.get( k );
+	int	hi = r.osd;
+	if( stp.loop && stp.maxglen != RMA_UNBOUNDED && r.zero + stp.maxglen - 1 < hi )
+		hi = r.zero + stp.maxglen - 1;
+	r.sd = int16_t( hi );
+	r.ph = 0;
+	gr.set( k, r );
+}
+
+template< class GR >
+RMD_FN int rmd_gen_begin( const rmd_program_t *P, GR &gr, rmd_gen_t &st, int szero, int slen, int r0, int cnt )
+{
+	st.szero = szero;
+	st.slen = slen;
+	st.rank = -1;
+	st.order = 0;
+	rmd_grec_t	r;
+	r.zero = 0;
+	r.osd = int16_t( rmd_imin( szero + P->w_winsize - 1, slen - 1 ) - szero );
+	r.sd = r.a = r.c = 0;
+	r.hl = r.ph = 0;
+	gr.set( 0, r );
+	rmd_gen_open( P, gr, 0 );
+	const rmd_elem_t	&stp = P->elems[ P->searches[ 0 ] ];
+	st.hi0 = gr.get( 0 ).sd;
+	st.lo0 = stp.minglen - 1;
+	st.pretested = cnt == 1 && stp.quick;	// (rank items of such a level are only made from end positions that passed it)
+	if( r0 > 0 || cnt != RMD_ALL_RANKS ){
+		r = gr.get( 0 );
+		r.sd = int16_t( st.hi0 - r0 );
+		if( cnt < st.hi0 - st.lo0 + 1 && r.sd - cnt + 1 > st.lo0 )
+			st.lo0 = r.sd - cnt + 1;
+		gr.set( 0, r );
+	}
+	return 0;
+}
+
+// Next end position of level k (find_motif :273-280): false when there is none left.
+template< class GR >
+RMD_FN bool rmd_gen_next_sd( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r, int *cur )
+{
+	const int	z = st.szero;
+	int	lo = stp.loop ? r.zero + stp.minglen - 1 : r.osd;
+	if( k == 0 && st.lo0 > lo )
+		lo = st.lo0;
+	if( stp.quick && !( k == 0 && st.pretested ) ){
+		// end positions whose first base pairs cannot start this helix are skipped at once: they
+		// have no effect that outlives the iteration (find_motif.c:273-280, 1010-1021)
+		while( r.sd >= lo && !rmd_quick_wchlx( P, stp, sq, z + r.zero, z + r.sd,
+			rmd_s3lim( r.zero, r.sd, stp.q_iminl, stp.maxlen ) + z ) )
+			r.sd--;
+	}
+	if( r.sd < lo )
+		return false;
+	*cur = r.sd--;
+	if( stp.loop ){
+		if( k == 0 ){
+			st.rank = st.hi0 - *cur;
+			st.order = 0;
+		}
+		if( stp.next_s >= 0 )
+			gr.set_window( stp.next_s, *cur + 1, r.osd );
+	}
+	return true;
+}
+
+// Advance level k to its next alternative: true with the alternative recorded in r and the
+// windows of the levels it opens set, false when the level is exhausted.
+template< class GR >
+RMD_FN bool rmd_gen_ss( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r )		// find_ss :332
+{
+	r.ph = 0;
+	for( int cur; rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ); ){
+		const int	len = cur - r.zero + 1;
+		if( len < stp.minlen || len > stp.maxlen )
+			continue;
+		if( stp.re >= 0 ){
+			int	mm = 0;
+			if( !rmd_chk_seq( P, stp, sq, st.szero + r.zero, len, &mm ) )
+				continue;
+		}
+		r.ph = 1;
+		return true;
+	}
+	return false;
+}
+
+template< class GR >
+RMD_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r )		// find_wchlx :400
+{
+	const int	z = st.szero, d = P->searches[ k ];
+	uint64_t	cand = 0, mis = 0;
+	int	cur = r.sd + 1, mm5 = 0, mm3 = 0;
+	if( r.ph != 0 ){
+		// back at the helix: its remaining lengths at the same end position
+		r.ph = 0;
+		rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
+			rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 );
+		cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+	}
+	for( ; ; ){
+		if( cand == 0 ){
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+				return false;
+			mm5 = mm3 = 0;
+			if( !rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
+				rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 ) ){
+				cand = 0;
+				continue;
+			}
+		}
+		const int	hl = rmd_ctz64( cand );		// find_wchlx :435-460
+		cand &= cand - 1;
+		if( cur - r.zero - 2 * hl + 1 > stp.maxilen )
+			continue;
+		r.hl = uint8_t( hl );
+		r.ph = 1;
+		gr.set_window( stp.inner_s, r.zero + hl, cur - hl );
+		return true;
+	}
+}
+
+// Improper helix: find_pknot :465, find_pknot5 :495, find_pknot3 :530.
+// Phases: 1 next 5' start, 2 next 3' end, 3 next helix length at (s5, s3).
+template< class GR >
+RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r )
+{
+	const int	z = st.szero, d = P->searches[ k ], d3 = stp.mates[ 0 ];
+	const rmd_pk_t	&pk = rmd_pks( P )[ stp.pk ];
+	uint64_t	cand = 0, mis = 0;
+	int	cur = r.sd + 1;			// end position in use (ph != 0)
+	int	i_minl = 0, i_maxl, l_s5 = 0, l_s3 = 0;
+	// the loop limits are functions of the helices matched above this level: recomputed on resume
+	auto s5_limits = [ & ]( int *f_s5 ) -> bool {		// find_pknot5 :510-522
+		int	p_minl, p_maxl, r_minl, r_maxl;
+		rmd_pk_len( pk, gr, RMD_PK_P, &p_minl, &p_maxl );
+		rmd_pk_len( pk, gr, RMD_PK_R, &r_minl, &r_maxl );
+		const int	slen = cur - r.zero + 1;
+		if( p_maxl + r_maxl < slen )
+			return false;
+		*f_s5 = r.zero + p_minl;
+		l_s5 = r.zero + rmd_imin( p_maxl, slen - r_minl );
+		return true;
+	};
+	auto s3_limits = [ & ]( int s5, int *f_s3 ) -> bool {	// find_pknot3 :555-568
+		int	s_minl, s_maxl;
+		rmd_pk_len( pk, gr, RMD_PK_I, &i_minl, &i_maxl );
+		rmd_pk_len( pk, gr, RMD_PK_S, &s_minl, &s_maxl );
+		const int	slen3 = cur - s5 + 1, g_minl = 2 * stp.minlen + i_minl;
+		if( g_minl + s_minl > slen3 )
+			return false;
+		*f_s3 = cur - s_minl;
+		l_s3 = cur - rmd_imin( slen3 - g_minl, s_maxl );
+		return true;
+	};
+	{
+		// back at the level: the limits it was left with
+		int	dummy;
+		if( r.ph >= 1 )
+			s5_limits( &dummy );
+		if( r.ph >= 2 )
+			s3_limits( r.a - 1, &dummy );
+		if( r.ph == 3 ){
+			const int	s5 = r.a - 1, s3 = r.c + 1;
+			int	mm5 = 0, mm3 = 0;
+			rmd_match_wchlx_mm( P, sq, d, d3, z + s5, z + s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 );
+			cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+		}
+	}
+	for( ; ; ){
+		if( r.ph == 0 ){
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+				return false;
+			if( stp.scope == 0 ){
+				// the other helices of the knot start from the knot's window, :476-487
+				for( int s = 1; s < stp.n_scopes; s++ )
+					if( P->elems[ stp.scopes[ s ] ].type == RMA_T_H5 )
+						gr.set_window( pk.lvl[ s ], r.zero, cur );
+			}
+			int	f_s5;
+			if( !s5_limits( &f_s5 ) )
+				continue;
+			r.a = int16_t( f_s5 );
+			r.ph = 1;
+		}
+		if( r.ph == 1 ){		// next 5' start, find_pknot5 :523 / find_pknot3 :548-568
+			if( r.a > l_s5 ){
+				r.ph = 0;
+				continue;
+			}
+			const int	s5 = r.a++;
+			if( !rmd_prefix_ok( P, stp, sq, z + s5 ) )
+				continue;
+			int	f_s3;
+			if( !s3_limits( s5, &f_s3 ) )
+				continue;
+			r.c = int16_t( f_s3 );
+			r.ph = 2;
+		}
+		if( r.ph == 2 ){		// next 3' end, find_pknot3 :600
+			const int	s5 = r.a - 1;
+			// 3' ends whose first pairs cannot start the helix change nothing: skip them
+			while( r.c >= l_s3 && !rmd_quick_wchlx( P, stp, sq, z + s5, z + r.c,
+				rmd_s3lim( s5, r.c, i_minl, stp.maxlen ) + z ) )
+				r.c--;
+			if( r.c < l_s3 ){
+				r.ph = 1;
+				continue;
+			}
+			const int	s3 = r.c--;
+			int	mm5 = 0, mm3 = 0;
+			if( !rmd_match_wchlx_mm( P, sq, d, d3, z + s5, z + s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ) + z,
+				&cand, &mis, &mm5, &mm3 ) )
+				continue;
+			r.ph = 3;
+		}
+		// ph == 3: next helix length at (s5, s3), find_pknot3 :607
+		const int	s5 = r.a - 1, s3 = r.c + 1;
+		bool	found = false;
+		int	hl = 0;
+		while( cand != 0 ){
+			hl = rmd_ctz64( cand );
+			cand &= cand - 1;
+			if( ( s3 - s5 + 1 ) - 2 * hl < i_minl ){
+				cand = 0;	// break: longer helices only get worse
+				break;
+			}
+			if( pk.hlx2 ){		// :571-627
+				const rmd_grec_t	h1 = gr.get( pk.lvl[ 0 ] );
+				const int	s3_h1 = h1.c + 1;
+				const int	iL_last = s3_h1 - h1.hl, iR_last = s3_h1 + 1;
+				int	iL_minl, iL_maxl, iR_minl, iR_maxl;
+				rmd_pk_len( pk, gr, RMD_PK_IL, &iL_minl, &iL_maxl );
+				rmd_pk_len( pk, gr, RMD_PK_IR, &iR_minl, &iR_maxl );
+				const int	il = iL_last - ( s5 + hl - 1 ), ir = ( s3 - hl + 1 ) - iR_last;
+				if( il < iL_minl || il > iL_maxl || ir < iR_minl || ir > iR_maxl )
+					continue;
+			}
+			found = true;
+			break;
+		}
+		if( !found ){
+			r.ph = 2;
+			continue;
+		}
+		r.hl = uint8_t( hl );
+		// upd_pksearches(), :667
+		if( pk.w_osd5 >= 0 )
+			gr.set_osd( pk.w_osd5, s5 - 1 );
+		if( pk.w_zero5 >= 0 )
+			gr.set_zero( pk.w_zero5, s5 + hl );
+		if( pk.w_osd3 >= 0 )
+			gr.set_osd( pk.w_osd3, s3 - hl );
+		if( pk.w_zero3 >= 0 )
+			gr.set_zero( pk.w_zero3, s3 + 1 );
+		return true;
+	}
+}
+
+template< class GR >
+RMD_COLD bool rmd_gen_phlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r )		// find_phlx :703
+{
+	const int	z = st.szero, d = P->searches[ k ];
+	r.ph = 0;
+	for( int cur; rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ); ){
+		int	s5hi, s5lo, hlen, n_mpr, mm5 = 0, mm3 = 0;
+		rmd_phlx_bounds( z + r.zero, cur - r.zero + 1, stp.minlen, stp.maxlen, stp.minilen, stp.maxilen, &s5hi, &s5lo );
+		if( !rmd_match_phlx( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur, s5hi, s5lo, &hlen, &n_mpr, &mm5, &mm3 ) )
+			continue;
+		if( cur - r.zero - 2 * hlen + 1 > stp.maxilen )
+			continue;
+		r.hl = uint8_t( hlen );
+		r.ph = 1;
+		gr.set_window( stp.inner_s, r.zero + hlen, cur - hlen );
+		return true;
+	}
+	return false;
+}
+
+template< class GR >
+RMD_COLD bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r )		// find_triplex :763
+{
+	const int	z = st.szero, d = P->searches[ k ], d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
+	const rmd_elem_t	&stp1 = P->elems[ d1 ];
+	int	cur = r.sd + 1;
+	for( ; ; ){
+		if( r.ph == 0 ){
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+				return false;
+			int	s5hi, s5lo, hlen, n_mpr, mm5 = 0, mm3 = 0;
+			rmd_phlx_bounds( z + r.zero, cur - r.zero + 1, stp.minlen, stp.maxlen, stp.minilen + stp1.minilen,
+				stp.maxilen + stp.minlen + stp1.maxilen, &s5hi, &s5lo );
+			if( !rmd_match_phlx( P, sq, d, d2, z + r.zero, z + cur, s5hi, s5lo, &hlen, &n_mpr, &mm5, &mm3 ) )
+				continue;
+			if( cur - r.zero - 2 * hlen + 1 > stp.maxilen + stp1.maxilen + hlen )
+				continue;
+			r.hl = uint8_t( hlen );
+			r.a = int16_t( cur - stp1.minilen - hlen );		// first end of the middle strand, :821
+			r.ph = 1;
+		}
+		const int	hlen = r.hl, last = r.zero + 2 * hlen + stp.minilen - 1;
+		while( r.a >= last ){
+			const int	s = r.a--;
+			int	n_mpr, mm1 = 0;
+			if( !rmd_match_triplex( P, sq, d, d1, z + r.zero, z + s, z + cur, hlen, &n_mpr, &mm1 ) )
+				continue;
+			if( s - 2 * hlen - r.zero + 1 > stp.maxilen )
+				continue;
+			if( cur - hlen - s > stp1.maxilen )
+				continue;
+			gr.set_window( stp.inner_s, r.zero + hlen, s - hlen );
+			gr.set_window( stp1.inner_s, s + 1, cur - hlen );
+			return true;
+		}
+		r.ph = 0;
+	}
+}
+
+// Phases: 1 next length of the outer helix, 2 next (s1, s2) of the inner strands.
+template< class GR >
+RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r )		// find_4plex :851, find_4plex_inner :902
+{
+	const int	z = st.szero, d = P->searches[ k ];
+	const int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
+	const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
+	const int	i_minl = stp.minilen + stp1.minilen + stp2.minilen + 2 * stp.minlen;
+	uint64_t	cand = 0, mis = 0;
+	int	cur = r.sd + 1;
+	bool	have_cand = false;		// cand holds the outer helix' lengths beyond r.hl
+	for( ; ; ){
+		if( r.ph == 0 ){
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+				return false;
+			int	mm5 = 0, mm3 = 0;
+			if( !rmd_match_wchlx_mm( P, sq, d, d3, z + r.zero, z + cur, rmd_s3lim( r.zero, cur, i_minl, stp.maxlen ) + z,
+				&cand, &mis, &mm5, &mm3 ) )
+				continue;
+			have_cand = true;
+			r.ph = 1;
+		}
+		if( r.ph == 1 ){		// next outer helix length, find_4plex :893
+			if( !have_cand ){
+				int	mm5 = 0, mm3 = 0;
+				rmd_match_wchlx_mm( P, sq, d, d3, z + r.zero, z + cur, rmd_s3lim( r.zero, cur, i_minl, stp.maxlen ) + z,
+					&cand, &mis, &mm5, &mm3 );
+				cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+				have_cand = true;
+			}
+			if( cand == 0 ){
+				r.ph = 0;
+				have_cand = false;
+				continue;
+			}
+			const int	hl = rmd_ctz64( cand );
+			cand &= cand - 1;
+			r.hl = uint8_t( hl );
+			r.a = int16_t( r.zero + hl + stp.minilen );		// s1
+			r.c = int16_t( cur - hl - stp2.minilen );		// s2
+			r.ph = 2;
+		}
+		// ph == 2: find_4plex_inner :902, s1 upwards, s2 downwards
+		const int	hl = r.hl;
+		const int	s1lim = cur - 3 * hl - stp2.minilen - stp1.minilen;
+		while( r.a <= s1lim ){
+			const int	s1 = r.a;
+			if( r.c < s1 + 2 * hl + stp1.minilen ){
+				r.a++;
+				r.c = int16_t( cur - hl - stp2.minilen );
+				continue;
+			}
+			const int	s2 = r.c--;
+			int	n_mpr, mm1 = 0, mm2 = 0;
+			if( !rmd_match_4plex( P, sq, d1, d2, z + r.zero, z + s1, z + s2, z + cur, hl, &n_mpr, &mm1, &mm2 ) )
+				continue;
+			if( s1 - r.zero - hl + 1 > stp.maxilen )
+				continue;
+			if( s2 - s1 - 2 * hl + 1 > stp1.maxilen )
+				continue;
+			if( cur - s2 - hl + 1 > stp2.maxilen )
+				continue;
+			gr.set_window( stp.inner_s, r.zero + hl, s1 - 1 );
+			gr.set_window( stp1.inner_s, s1 + hl, s2 - hl );
+			gr.set_window( stp2.inner_s, s2 + 1, cur - hl );
+			return true;
+		}
+		r.ph = 1;
+		have_cand = false;
+	}
+}
+
+// Rebuild the element table of the current path into L (every level holds an alternative)
+// and run the end-of-list checks (find_ss :362-393).
+template< class GR, class Sink >
+RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, rmd_lane_t *L, Sink &sink )
+{
+	const int	z = st.szero;
+	for( int k = 0; k < P->n_searches; k++ ){
+		const rmd_grec_t	r = gr.get( k );
+		const int	d = P->searches[ k ];
+		const rmd_elem_t	&stp = P->elems[ d ];
+		const int	zero = z + r.zero, cur = z + r.sd + 1;
+		switch( stp.type ){
+		case RMA_T_SS : {
+			int	mm = 0;
+			if( stp.re >= 0 && stp.mismatch > 0 )
+				rmd_chk_seq( P, stp, sq, zero, cur - zero + 1, &mm );
+			L->moff[ d ] = zero;
+			L->mlen[ d ] = cur - zero + 1;
+			L->mpr[ d ] = 0;
+			L->mm[ d ] = int16_t( mm );
+			break;
+		}
+		case RMA_T_H5 : {
+			const int	d3 = stp.mates[ 0 ], hl = r.hl;
+			uint64_t	cand, mis;
+			int	s5 = zero, s3 = cur, i_minl = stp.minilen, mm5 = 0, mm3 = 0;
+			if( !stp.proper ){
+				// s_n_mismatches of a knot's strands is not reset per attempt (find_pknot3): what
+				// the search started with unless this match's chk_seq() calls count them
+				int	i_maxl;
+				s5 = z + r.a - 1;
+				s3 = z + r.c + 1;
+				rmd_pk_len( rmd_pks( P )[ stp.pk ], gr, RMD_PK_I, &i_minl, &i_maxl );
+				mm5 = mm3 = RMD_UNDEF;
+			}
+			rmd_match_wchlx_mm( P, sq, d, d3, s5, s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
+			const int	mpr = rmd_popc64( mis & ( ( 1ull << hl ) - 1 ) );
+			L->moff[ d ] = s5;
+			L->mlen[ d ] = hl;
+			L->moff[ d3 ] = s3 - hl + 1;
+			L->mlen[ d3 ] = hl;
+			L->mpr[ d ] = L->mpr[ d3 ] = int16_t( mpr );
+			L->mm[ d ] = int16_t( mm5 );
+			L->mm[ d3 ] = int16_t( mm3 );
+			break;
+		}
+		case RMA_T_P5 : {
+			const int	d3 = stp.mates[ 0 ];
+			int	s5hi, s5lo, hlen = 0, n_mpr = 0, mm5 = 0, mm3 = 0;
+			rmd_phlx_bounds( zero, cur - zero + 1, stp.minlen, stp.maxlen, stp.minilen, stp.maxilen, &s5hi, &s5lo );
+			rmd_match_phlx( P, sq, d, d3, zero, cur, s5hi, s5lo, &hlen, &n_mpr, &mm5, &mm3 );
+			L->moff[ d ] = zero;
+			L->mlen[ d ] = hlen;
+			L->moff[ d3 ] = cur - hlen + 1;
+			L->mlen[ d3 ] = hlen;
+			L->mpr[ d ] = L->mpr[ d3 ] = int16_t( n_mpr );
+			L->mm[ d ] = int16_t( mm5 );
+			L->mm[ d3 ] = int16_t( mm3 );
+			break;
+		}
+		case RMA_T_T1 : {
+			const int	d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
+			const rmd_elem_t	&stp1 = P->elems[ d1 ];
+			int	s5hi, s5lo, hlen = 0, n_mpr = 0, mm5 = 0, mm3 = 0, mm1 = 0;
+			rmd_phlx_bounds( zero, cur - zero + 1, stp.minlen, stp.maxlen, stp.minilen + stp1.minilen,
+				stp.maxilen + stp.minlen + stp1.maxilen, &s5hi, &s5lo );
+			rmd_match_phlx( P, sq, d, d2, zero, cur, s5hi, s5lo, &hlen, &n_mpr, &mm5, &mm3 );
+			const int	s = z + r.a + 1;
+			rmd_match_triplex( P, sq, d, d1, zero, s, cur, hlen, &n_mpr, &mm1 );
+			L->moff[ d ] = zero;
+			L->moff[ d1 ] = s - hlen + 1;
+			L->moff[ d2 ] = cur - hlen + 1;
+			L->mlen[ d ] = L->mlen[ d1 ] = L->mlen[ d2 ] = hlen;
+			L->mpr[ d ] = L->mpr[ d1 ] = L->mpr[ d2 ] = int16_t( n_mpr );
+			L->mm[ d ] = int16_t( mm5 );
+			L->mm[ d1 ] = int16_t( mm1 );
+			L->mm[ d2 ] = int16_t( mm3 );
+			break;
+		}
+		case RMA_T_Q1 : {
+			const int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ], hl = r.hl;
+			const int	i_minl = stp.minilen + P->elems[ d1 ].minilen + P->elems[ d2 ].minilen + 2 * stp.minlen;
+			uint64_t	cand, mis;
+			int	n_mpr = 0, mm5 = 0, mm3 = 0, mm1 = 0, mm2 = 0;
+			rmd_match_wchlx_mm( P, sq, d, d3, zero, cur, rmd_s3lim( zero, cur, i_minl, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
+			const int	s1 = z + r.a, s2 = z + r.c + 1;
+			rmd_match_4plex( P, sq, d1, d2, zero, s1, s2, cur, hl, &n_mpr, &mm1, &mm2 );
+			L->moff[ d ] = zero;
+			L->moff[ d1 ] = s1;
+			L->moff[ d2 ] = s2 - hl + 1;
+			L->moff[ d3 ] = cur - hl + 1;
+			L->mlen[ d ] = L->mlen[ d1 ] = L->mlen[ d2 ] = L->mlen[ d3 ] = hl;
+			L->mpr[ d ] = L->mpr[ d1 ] = L->mpr[ d2 ] = L->mpr[ d3 ] = int16_t( n_mpr );
+			L->mm[ d ] = int16_t( mm5 );
+			L->mm[ d1 ] = int16_t( mm1 );
+			L->mm[ d2 ] = int16_t( mm2 );
+			L->mm[ d3 ] = int16_t( mm3 );
+			break;
+		}
+		default :
+			break;
+		}
+	}
+	L->slen = st.slen;
+	L->szero = z;
+	L->rank = st.rank;
+	L->order = st.order;
+	L->l_mm = L->r_mm = RMD_UNDEF;
+	L->l_off = L->l_len = L->r_off = L->r_len = 0;
+	if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
+		return;
+	if( !rmd_set_context( P, L, sq ) )
+		return;
+	if( !rmd_chk_sites( P, L, sq ) )
+		return;
+	sink.put( P, L, z );
+	st.order++;
+}
+
+// One transition at level k; returns the next level, -1 when the item is done.
+template< class GR, class Sink >
+RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k, rmd_lane_t *L, Sink &sink )
+{
+	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
+	rmd_grec_t	r = gr.get( k );
+	bool	ok;
+	switch( stp.type ){
+	case RMA_T_SS :
+		ok = rmd_gen_ss( P, gr, st, sq, k, stp, r );
+		break;
+	case RMA_T_H5 :
+		ok = stp.proper ? rmd_gen_wchlx( P, gr, st, sq, k, stp, r ) : rmd_gen_pknot( P, gr, st, sq, k, stp, r );
+		break;
+	case RMA_T_P5 :
+		ok = rmd_gen_phlx( P, gr, st, sq, k, stp, r );
+		break;
+	case RMA_T_T1 :
+		ok = rmd_gen_triplex( P, gr, st, sq, k, stp, r );
+		break;
+	case RMA_T_Q1 :
+		ok = rmd_gen_4plex( P, gr, st, sq, k, stp, r );
+		break;
+	default :
+		ok = false;
+		break;
+	}
+	if( !ok )
+		return k - 1;
+	gr.set_iter( k, r );
+	if( k < P->n_searches - 1 ){
+		rmd_gen_open( P, gr, k + 1 );
+		return k + 1;
+	}
+	rmd_gen_emit( P, gr, st, sq, L, sink );
+	return k;
+}
+
+// The search for one start position (one iteration of RM_find_motif's loops,
+// find_motif.c:184-205), restricted to ranks r0 .. r0+cnt-1 of the first element.
+template< class GR, class Sink >
+RMD_FN void rmd_gen_position( const rmd_program_t *P, GR &gr, rmd_lane_t *L, const rmd_seq_t &sq,
+	int szero, int slen, int r0, int cnt, Sink &sink )
+{
+	rmd_gen_t	st;
+	int	k = rmd_gen_begin( P, gr, st, szero, slen, r0, cnt );
+	while( k >= 0 )
+		k = rmd_gen_step( P, gr, st, sq, k, L, sink );
 }

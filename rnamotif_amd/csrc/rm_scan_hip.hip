@@ -118,6 +118,54 @@ struct LdsRecs {
 	}
 };
 
+// General path records of one lane in LDS (rmd_grec_t, 12 bytes per level): three dwords at
+// w[ ( 3 * k + j ) * BLOCK ], lane-contiguous, so a wave's access is conflict free whatever
+// levels its lanes are on.  Dword 0: window start | saved window end; dword 1: next end position |
+// first loop variable; dword 2: second loop variable | helix length | phase.
+#define GEN_REC_BYTES	12
+template< int BLOCK >
+struct LdsGRecs {
+	uint32_t	*w;
+	__device__ inline rmd_grec_t	get( int k ) const
+	{
+		const uint32_t	d0 = w[ ( 3 * k ) * BLOCK ], d1 = w[ ( 3 * k + 1 ) * BLOCK ], d2 = w[ ( 3 * k + 2 ) * BLOCK ];
+		rmd_grec_t	r;
+		r.zero = int16_t( d0 & 0xffffu );
+		r.osd = int16_t( d0 >> 16 );
+		r.sd = int16_t( d1 & 0xffffu );
+		r.a = int16_t( d1 >> 16 );
+		r.c = int16_t( d2 & 0xffffu );
+		r.hl = uint8_t( ( d2 >> 16 ) & 0xffu );
+		r.ph = uint8_t( d2 >> 24 );
+		return r;
+	}
+	__device__ inline void	set_iter( int k, rmd_grec_t v )
+	{
+		w[ ( 3 * k + 1 ) * BLOCK ] = ( uint32_t( uint16_t( v.sd ) ) ) | ( uint32_t( uint16_t( v.a ) ) << 16 );
+		w[ ( 3 * k + 2 ) * BLOCK ] = ( uint32_t( uint16_t( v.c ) ) ) | ( uint32_t( v.hl ) << 16 ) | ( uint32_t( v.ph ) << 24 );
+	}
+	__device__ inline void	set_window( int k, int zero, int osd )
+	{
+		w[ ( 3 * k ) * BLOCK ] = ( uint32_t( zero ) & 0xffffu ) | ( uint32_t( osd ) << 16 );
+	}
+	__device__ inline void	set( int k, rmd_grec_t v )
+	{
+		set_window( k, v.zero, v.osd );
+		set_iter( k, v );
+	}
+	__device__ inline void	set_zero( int k, int zero )
+	{
+		uint32_t	&d0 = w[ ( 3 * k ) * BLOCK ];
+		d0 = ( d0 & 0xffff0000u ) | ( uint32_t( zero ) & 0xffffu );
+	}
+	__device__ inline void	set_osd( int k, int osd )
+	{
+		uint32_t	&d0 = w[ ( 3 * k ) * BLOCK ];
+		d0 = ( d0 & 0xffffu ) | ( uint32_t( osd ) << 16 );
+	}
+	__device__ inline int	hl( int k ) const { return int( ( w[ ( 3 * k + 2 ) * BLOCK ] >> 16 ) & 0xffu ); }
+};
+
 // 64 bits of a bit vector starting at bit q: three dwords through two v_alignbit_b32
 __device__ inline unsigned long long bits64( const unsigned long long *row, int q )
 {
@@ -180,7 +228,7 @@ struct TailAccel {
 // (the general instance keeps its frames in scratch and is latency bound on them: six
 // waves per SIMD at 80 VGPRs beat four at 128 -- pk1 48.5 -> 41.9 ms, qu+tr 124 -> 94 ms)
 #ifndef GENERAL_WAVES_PER_SIMD
-#define GENERAL_WAVES_PER_SIMD	6
+#define GENERAL_WAVES_PER_SIMD	4
 #endif
 #ifndef SHORT_GROUP
 #define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
@@ -240,6 +288,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * 6 * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
 	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
+	LdsGRecs<BLOCK>	gr{ lean_lo + threadIdx.x };		// (the general instance's records take the same place)
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
 	const int	lit_n = lit ? rmd_regexes( P )[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
@@ -274,6 +323,15 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// the lane that found it.
 	unsigned	*const spill = hb.spill + size_t( blockIdx.x ) * hb.spill_cap;
 	const int	qtotal = qcap + hb.spill_cap;
+	// diagnostic (RNAMOTIF_DBG bit 32): wave cycles per phase, summed over all waves, into the counters behind
+	// the ticket: 0 ticket + decode, 1 literal vector, 2 pair rows, 3 pre-filter loop, 4 search, 5 waiting for the tile's end
+	unsigned long long	t_ph = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
+#define PHASE( i_ )	do{ if( dbg & 32 ){ \
+			const unsigned long long	now_ = __builtin_amdgcn_s_memtime(); \
+			if( ( threadIdx.x & 63 ) == 0 ) \
+				atomicAdd( hb.ticket + 3 + ( i_ ), now_ - t_ph ); \
+			t_ph = now_; \
+		} }while( 0 )
 	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
 	for( ; ; ){
 		if( tid == 0 ){
@@ -343,6 +401,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			}
 		}
 		SLOT_SYNC();
+		PHASE( 0 );
 		// short entries fill only part of a tile: the loops below run over what is there
 		const int	pos_end = rmd_imin( slen - P->dminlen + 1, pos_hi );
 		const int	n_pos = live ? rmd_imin( T, pos_end - z0 ) : 0;		// start positions of this tile
@@ -378,6 +437,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					occ[ base >> 6 ] = m;
 			}
 			SLOT_SYNC();
+			PHASE( 1 );
 		}
 		// does the literal start anywhere in [a_, b_] (absolute positions)?
 #define LIT_IN( a_, b_, res_ )	do{ \
@@ -416,7 +476,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					while( k_ >= 0 ) \
 						k_ = rmd_lean_step( P, lr, st_, sq, k_, &lane, sink ); \
 				}else \
-					rmd_search_position( P, &lane, sq, szero_, slen, r0_, cnt_, sink ); \
+					rmd_gen_position( P, gr, &lane, sq, szero_, slen, r0_, cnt_, sink ); \
 			} \
 		} }while( 0 )
 
@@ -436,6 +496,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 			}
 			SLOT_SYNC();
+			PHASE( 2 );
 			const int	hl0 = e0.minlen;
 			// superset of match_wchlx's rule (find_motif.c:1010-1033,1065-1080): at most mplim
 			// mispairs among the first minlen pairs; an unpaired first pair is allowed only if
@@ -499,15 +560,28 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					// lies between s5 + 2*minlen + interior - 1 and the window end minus what must
 					// follow it; search the position only if some end there can start the helix
 					bool	any = false;
-					if( valid ){
-						const int	top = hi - e0.q_sminl, bot = szero + 2 * e0.minlen + e0.q_iminl - 1;
-						for( int r0 = 0; !any && r0 <= top - bot; r0 += 64 )
-							any = win( szero, top, r0, bot ) != 0;
-						any = any && rmd_prefix_ok( P, e0, sq, szero );
+					unsigned long long	W0 = 0;		// 3' ends top-63 .. top that can, when the whole range is one word
+					const int	top = hi - e0.q_sminl, bot = szero + 2 * e0.minlen + e0.q_iminl - 1;
+					const bool	one_word = top - bot < 64 && e0.q_smaxl >= 0;
+					if( valid && rmd_prefix_ok( P, e0, sq, szero ) ){
+						if( one_word ){
+							W0 = top >= bot ? win( szero, top, 0, bot ) : 0;
+							any = W0 != 0;
+						}else
+							for( int r0 = 0; !any && r0 <= top - bot; r0 += 64 )
+								any = win( szero, top, r0, bot ) != 0;
 					}
+					if( __ballot( any ) == 0 )
+						continue;		// (nothing to queue for these 64 positions)
 					if( split_ranks ){
 						for( int r = 0; r < n_rank; r++ ){
 							bool	pred = any && r <= hi - lo;
+							if( pred && one_word ){
+								// this rank's end leaves the 3' strand the ends hi-r-q_smaxl .. hi-r-q_sminl
+								// (find_pknot3 :566-568): bits 63-r-(q_smaxl-q_sminl) .. 63-r of W0
+								const int	i_hi = 63 - r, i_lo = rmd_imax( i_hi - ( e0.q_smaxl - e0.q_sminl ), 0 );
+								pred = i_hi >= 0 && ( ( W0 >> i_lo ) & ( i_hi - i_lo >= 63 ? ~0ull : ( 2ull << ( i_hi - i_lo ) ) - 1 ) ) != 0;
+							}
 							if( pred && P->lit_ehi >= 0 ){
 								// the rank fixes the end of the knot: the literal must also sit at
 								// an admissible distance from that end
@@ -519,6 +593,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 								else
 									LIT_IN( a_, b_, pred );
 							}
+							if( __ballot( pred ) == 0 )
+								continue;
 							QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
 						}
 					}else
@@ -588,9 +664,11 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 #undef QPUSH
 #undef LIT_OK
 #undef LIT_IN
+		PHASE( 3 );
 		}	// slots
 #undef SLOT_SYNC
 		__syncthreads();
+		PHASE( 5 );
 
 		// ---- pass B: the full search.  Lanes are persistent within the tile: a lane
 		// that finishes its item pops the next one at once (wave-aggregated pop), so a
@@ -668,33 +746,39 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( k >= 0 )
 					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink, accel );
 			}
-		}else
-		for( ; ; ){
-			const unsigned long long	want = __ballot( k < 0 && !dry );
-			if( want ){
-				int	base = 0;
-				if( lane_id == __ffsll( want ) - 1 )
-					base = atomicAdd( &s_qhead, __popcll( want ) );
-				base = __shfl( base, __ffsll( want ) - 1 );
-				if( k < 0 && !dry ){
-					const int	i = base + __popcll( want & lt_mask );
-					if( i < nq ){
-						const unsigned	item = i < qcap ? queue[ i ] :
-							__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-						const int	r = int( item & 0xffffu );
-						k = rmd_search_begin( P, &lane, z0 + int( item >> 16 ), slen,
-							r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
-					}else
-						dry = true;
+		}else{
+			// every element type: 12 bytes of search state per level, in LDS (rmd_grec_t)
+			rmd_gen_t	st;
+			for( ; ; ){
+				const unsigned long long	want = __ballot( k < 0 && !dry );
+				if( want ){
+					int	base = 0;
+					if( lane_id == __ffsll( want ) - 1 )
+						base = atomicAdd( &s_qhead, __popcll( want ) );
+					base = __shfl( base, __ffsll( want ) - 1 );
+					if( k < 0 && !dry ){
+						const int	i = base + __popcll( want & lt_mask );
+						if( i < nq ){
+							const unsigned	item = i < qcap ? queue[ i ] :
+								__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+							const int	r = int( item & 0xffffu );
+							k = rmd_gen_begin( P, gr, st, z0 + int( item >> 16 ), slen,
+								r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+						}else
+							dry = true;
+					}
 				}
+				if( __ballot( k >= 0 ) == 0 )
+					break;
+				if( k >= 0 )
+					k = rmd_gen_step( P, gr, st, sq, k, &lane, sink );
 			}
-			if( __ballot( k >= 0 ) == 0 )
-				break;
-			if( k >= 0 )
-				k = rmd_search_step( P, &lane, sq, k, sink );
 		}
+		PHASE( 4 );
 		__syncthreads();
+		PHASE( 5 );
 	}
+#undef PHASE
 }
 
 // ---------------------------------------------------------------- efn kernel
@@ -832,8 +916,7 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 	const size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
-	if( lean )
-		lds += size_t( dp.n_searches ) * 256 * LEAN_REC_BYTES;
+	lds += size_t( dp.n_searches ) * 256 * ( lean ? LEAN_REC_BYTES : GEN_REC_BYTES );
 	return lds;
 }
 
@@ -877,7 +960,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		HIPCHK( hipMalloc( &sc->d_prog, size_t( sc->prog_bytes ) ) );
 		HIPCHK( hipMemcpy( sc->d_prog, img.data(), size_t( sc->prog_bytes ), hipMemcpyHostToDevice ) );
 	}
-	HIPCHK( hipMalloc( &sc->d_counters, 4 * sizeof( unsigned long long ) ) );
+	HIPCHK( hipMalloc( &sc->d_counters, 16 * sizeof( unsigned long long ) ) );
 	if( efn != nullptr ){
 		std::vector<int16_t>	t16;
 		std::vector<int32_t>	tlkey;
@@ -956,16 +1039,19 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 			sc->qcap += 256;
 	}
 	if( !sc->dprog.lean_ok ){
-		// general instance: LDS is not what limits it (frames live in scratch), so larger tiles
-		// (pk1 41.9 -> 32 ms, qu+tr 94 -> 87 ms at 4096 with a queue that held all their items;
-		// with the queue's spill area a 1024-entry queue and tiles of 8192 positions: pk1 27.8,
-		// qu+tr 74 ms; 12288: 30.0 / 81) as long as six workgroups share a CU's LDS
+		// general instance: its records take 12 bytes per level and lane of LDS next to the tile;
+		// as many workgroups per CU as still leave a tile of a few thousand positions
 		sc->qcap = 1024;
-		sc->tile_t = 8192;
-		if( sc->spill_cap < 4096 ||
-			search_lds_bytes( sc->prog_bytes, sc->dprog, sc->tile_t, false, sc->qcap ) > ( 160 * 1024 ) / GENERAL_WAVES_PER_SIMD - 64 ){
-			sc->tile_t = 4096;
-			sc->qcap = 4096;
+		sc->tile_t = 1024;
+		bool	found = false;
+		for( int wg = GENERAL_WAVES_PER_SIMD; wg >= 1 && !found; wg-- ){
+			const size_t	budget = ( 160 * 1024 ) / wg - 64;
+			for( int t = 8192; t >= ( wg > 1 ? 4096 : 1024 ); t -= 256 )
+				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, false, sc->qcap ) <= budget ){
+					sc->tile_t = t;
+					found = true;
+					break;
+				}
 		}
 	}
 	if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )
@@ -1227,7 +1313,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	int	grid = int( std::min<int64_t>( n_units, sc->grid_blocks ) );
 	unsigned long long	count = 0;
 	for( int attempt = 0; attempt < 2; attempt++ ){
-		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 4 * sizeof( unsigned long long ), sc->stream ) );
+		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 16 * sizeof( unsigned long long ), sc->stream ) );
 		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		if( grouped )
@@ -1248,6 +1334,15 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 			( void )hipMemcpy( &q, sc->d_counters + 2, sizeof( q ), hipMemcpyDeviceToHost );
 			fprintf( stderr, "[dbg] queued items: %llu, candidates %llu (tile %d x %d, queue %d, LDS %zu, %lld tiles)\n", q, count,
 				db->tile_t, grouped ? db->group : 1, db->qcap, lds, ( long long )db->n_tiles );
+			if( dbg & 32 ){
+				unsigned long long	ph[ 6 ];
+				( void )hipMemcpy( ph, sc->d_counters + 4, sizeof( ph ), hipMemcpyDeviceToHost );
+				double	tot = 0;
+				for( int i = 0; i < 6; i++ )
+					tot += double( ph[ i ] );
+				fprintf( stderr, "[dbg] wave cycles: decode %.1f%%, literal %.1f%%, rows %.1f%%, pre-filter %.1f%%, search %.1f%%, waiting %.1f%%\n",
+					100 * ph[ 0 ] / tot, 100 * ph[ 1 ] / tot, 100 * ph[ 2 ] / tot, 100 * ph[ 3 ] / tot, 100 * ph[ 4 ] / tot, 100 * ph[ 5 ] / tot );
+			}
 		}
 		if( int64_t( count ) <= sc->hit_cap )
 			break;

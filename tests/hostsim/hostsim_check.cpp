@@ -50,6 +50,18 @@ struct ArrRecs {
 	void	set( int k, rmd_lrec_t v ) { r[ k ] = v; }
 };
 
+// the general path's records, one per search level (the kernel keeps them packed in LDS)
+struct GenRecs {
+	rmd_grec_t	r[ RMD_MAX_ELEMS ];
+	rmd_grec_t	get( int k ) const { return r[ k ]; }
+	void	set( int k, rmd_grec_t v ) { r[ k ] = v; }
+	void	set_iter( int k, rmd_grec_t v ) { r[ k ].sd = v.sd; r[ k ].a = v.a; r[ k ].c = v.c; r[ k ].hl = v.hl; r[ k ].ph = v.ph; }
+	void	set_window( int k, int zero, int osd ) { r[ k ].zero = int16_t( zero ); r[ k ].osd = int16_t( osd ); }
+	void	set_zero( int k, int zero ) { r[ k ].zero = int16_t( zero ); }
+	void	set_osd( int k, int osd ) { r[ k ].osd = int16_t( osd ); }
+	int	hl( int k ) const { return r[ k ].hl; }
+};
+
 // one work item, through the lean path when the descriptor allows it
 static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t &sq, int szero, int slen, int r0, int cnt, VecSink &sink )
 {
@@ -59,8 +71,11 @@ static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t
 		int	k = rmd_lean_begin( dp, recs, st, szero, slen, r0, cnt );
 		while( k >= 0 )
 			k = rmd_lean_step( dp, recs, st, sq, k, lane, sink );
-	}else
-		rmd_search_position( dp, lane, sq, szero, slen, r0, cnt, sink );
+	}else{
+		GenRecs	recs;
+		memset( &recs, 0x55, sizeof( recs ) );	// (windows are written before they are read: any garbage must do)
+		rmd_gen_position( dp, recs, lane, sq, szero, slen, r0, cnt, sink );
+	}
 }
 
 static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int slen, int comp, std::vector<int32_t> &out )
@@ -195,8 +210,7 @@ int main( int argc, char **argv )
 			fclose( fp );
 		}
 #ifdef RMD_STATS
-		fprintf( stderr, "stats: items %lld, rmd_next calls %lld, inner iterations %lld (ph0 ss %lld, ph0 other %lld), match_wchlx %lld\n",
-			rmd_stat[ 5 ], rmd_stat[ 0 ], rmd_stat[ 1 ], rmd_stat[ 2 ], rmd_stat[ 3 ], rmd_stat[ 4 ] );
+		fprintf( stderr, "stats: match_wchlx %lld\n", rmd_stat[ 4 ] );
 #endif
 		printf( "%s: %lld candidates, %lld mismatching strands", args.dfname.c_str(), ( long long )total, ( long long )bad );
 		if( n_efn2 > 0 )
