@@ -53,7 +53,7 @@ def main():
             if dbg is None:
                 out["candidates"] = n
                 out["efn_ms"] = round(e_ms, 3)
-        os.environ["RNAMOTIF_DBG"] = "2"
+        os.environ["RNAMOTIF_DBG"] = "34"     # 2: count queued items, 32: wave cycles per phase
         sys.stderr.flush()
         sc.scan_device(db)      # prints "[dbg] queued items" on stderr
         os.environ.pop("RNAMOTIF_DBG", None)

@@ -252,6 +252,69 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		if( !( e.type == RMA_T_SS || ( e.type == RMA_T_H5 && e.proper ) ) )
 			out->lean_ok = 0;
 	}
+	// ss elements that head a level: early tests of an anchored seq= (rmd_elem_t::pin_start/pin_end_n)
+	for( int d = 0; d < p->n_elems; d++ ){
+		rmd_elem_t	&e = out->elems[ d ];
+		e.pin_start = e.pin_end_n = 0;
+		if( e.type != RMA_T_SS || e.re < 0 || e.mismatch != 0 || p->elems[ d ].searchno < 0 )
+			continue;
+		const rmd_regex_t	&re = out->regexes[ e.re ];
+		e.pin_start = re.anchored && re.n_prefix > 0;
+		if( !e.loop && re.dollar && re.fixed_len > 0 && re.fixed_len <= 63 && re.opt == 0 && re.star == 0 )
+			e.pin_end_n = int8_t( re.fixed_len );
+	}
+	// first-tuple masks of the triplex / 4-plex pair tables
+	int	n_tups = 0;
+	for( int d = 0; d < p->n_elems; d++ )
+		out->elems[ d ].tup = -1;
+	for( int s = 0; s < p->n_searches; s++ ){
+		rmd_elem_t	&e = out->elems[ p->searches[ s ] ];
+		if( !( e.type == RMA_T_T1 || e.type == RMA_T_Q1 ) || e.pairset < 0 || n_tups == RMD_MAX_TUP )
+			continue;
+		// (match_4plex reads the pair table of the second strand, match_triplex that of the first:
+		// one table per group, compile.c hands every strand the group's)
+		const int	ps = e.type == RMA_T_Q1 ? out->elems[ e.mates[ 0 ] ].pairset : e.pairset;
+		if( ps < 0 )
+			continue;
+		const rmd_pairset_t	&t = out->pairsets[ ps ];
+		rmd_tup_t	&u = out->tups[ n_tups ];
+		memset( &u, 0, sizeof( u ) );
+		auto tri = [&]( int a, int b, int c ){ const int ix = ( a * 5 + b ) * 5 + c; return ( t.mat3[ ix >> 5 ] >> ( ix & 31 ) ) & 1; };
+		auto quad = [&]( int a, int b, int c, int dd ){ const int ix = ( ( a * 5 + b ) * 5 + c ) * 5 + dd; return ( t.mat4[ ix >> 5 ] >> ( ix & 31 ) ) & 1; };
+		for( int a = 0; a < 5; a++ )
+			for( int c = 0; c < 5; c++ )
+				for( int b = 0; b < 5; b++ ){
+					if( tri( a, b, c ) )
+						u.t2[ a * 5 + c ] |= uint8_t( 1u << b );
+					for( int x = 0; x < 5; x++ )
+						if( quad( a, b, x, c ) ){
+							u.q2[ a * 5 + c ] |= uint8_t( 1u << b );
+							u.q3[ ( a * 5 + b ) * 5 + c ] |= uint8_t( 1u << x );
+						}
+				}
+		e.tup = int8_t( n_tups++ );
+	}
+	out->n_tups = n_tups;
+	// pair row sets: one per distinct pair table of the helices that are matched with
+	// match_wchlx() at a search level and whose first-pairs rule fits the bit-parallel test
+	out->n_rowsets = 0;
+	for( int d = 0; d < p->n_elems; d++ )
+		out->elems[ d ].rows = -1;
+	for( int s = 0; s < p->n_searches; s++ ){
+		rmd_elem_t	&d = out->elems[ p->searches[ s ] ];
+		if( !( d.type == RMA_T_H5 || d.type == RMA_T_Q1 ) || d.pairset < 0 || d.minlen < 1 || d.mplim > 3 )
+			continue;
+		int	k;
+		for( k = 0; k < out->n_rowsets; k++ )
+			if( out->rowset_ps[ k ] == d.pairset )
+				break;
+		if( k == out->n_rowsets ){
+			if( out->n_rowsets == 4 )
+				continue;
+			out->rowset_ps[ out->n_rowsets++ ] = d.pairset;
+		}
+		d.rows = int8_t( k );
+	}
 	// improper helices: the sums find_pknot5/find_pknot3 take over ranges of the knot (rmd_pk_t)
 	int	n_pks = 0;
 	for( int d = 0; d < p->n_elems; d++ )
@@ -473,6 +536,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 	out->off_rules = int32_t( offsetof( rmd_program_t, rules ) );
 	out->off_pairsets = int32_t( offsetof( rmd_program_t, pairsets ) );
 	out->off_pks = int32_t( offsetof( rmd_program_t, pks ) );
+	out->off_tups = int32_t( offsetof( rmd_program_t, tups ) );
 	out->image_bytes = int32_t( sizeof( rmd_program_t ) );
 	return 0;
 #undef FAIL
@@ -503,6 +567,9 @@ size_t rmd_make_image( const rmd_program_t *full, void *img )
 	hdr->off_pks = int32_t( n );
 	memcpy( out + n, full->pks, size_t( full->n_pks ) * sizeof( rmd_pk_t ) );
 	n += size_t( full->n_pks ) * sizeof( rmd_pk_t );
+	hdr->off_tups = int32_t( n );
+	memcpy( out + n, full->tups, size_t( full->n_tups ) * sizeof( rmd_tup_t ) );
+	n += size_t( full->n_tups ) * sizeof( rmd_tup_t );
 	n = align( n, 16 );
 	hdr->image_bytes = int32_t( n );
 	return n;

@@ -68,9 +68,28 @@ struct rmd_elem_t {
 	int8_t	tail_s;			// helix: level of the last group of its interior if that is a
 					// proper helix (its 3' end is pinned to the interior's end), else -1
 	int8_t	pk;			// improper helix: index into pks[], else -1
-	int8_t	pad_[ 2 ];
+	int8_t	rows;			// Watson-Crick helix heading a level: pair row set of its pair table
+					// (rmd_program_t::rowset_ps), -1: none
+	int8_t	tup;			// t1 / q1: index into tups[] (first-tuple masks), else -1
 	int16_t	tail_pre_min, tail_pre_max;	// total length of the interior groups before it (-1: unbounded)
+	// ss heading a level, seq= without mismatches: what can be tested as soon as a level above pins
+	// its window (necessary conditions for chk_seq() on the final string, output neutral)
+	int8_t	pin_start;		// ^-anchored: its leading mandatory positions at the window start
+	int8_t	pin_end_n;		// > 0: the ss is its whole window and the expression is $-anchored with
+					// this fixed length: its last pin_end_n bases, once the window end is known
+	int8_t	pad2_[ 2 ];
 };
+
+// First-tuple masks of a triplex / 4-plex pair table: match_triplex()/match_4plex() give up at
+// once when the first triple / quad does not hold and the 5' end must be paired (find_motif.c:
+// 1198-1206, 1249-1257); which bases can complete it, given the others, is a 5-bit mask.
+struct rmd_tup_t {
+	uint8_t	t2[ 25 ];		// [ b1 * 5 + b3 ]: second bases b2 with triple( b1, b2, b3 )
+	uint8_t	q2[ 25 ];		// [ b1 * 5 + b4 ]: second bases b2 with quad( b1, b2, b3, b4 ) for some b3
+	uint8_t	q3[ 125 ];		// [ ( b1 * 5 + b2 ) * 5 + b4 ]: third bases b3 with quad( b1, b2, b3, b4 )
+	uint8_t	pad_[ 1 ];
+};
+#define RMD_MAX_TUP	8
 
 // Improper (pseudoknot) helix: what find_pknot5()/find_pknot3() compute with find_minlen()/
 // find_maxlen() (find_motif.c:495-665) over ranges of the knot's elements.  When helix i of a
@@ -127,8 +146,12 @@ struct rmd_program_t {
 	// what the descriptor uses: the members up to elems[ n_elems ], then the used regexes,
 	// rules and pair sets back to back (rmd_make_image()).  In this full struct the offsets
 	// point at the arrays below.
-	int32_t	n_regexes, n_rules, n_pairsets, n_pks;
-	int32_t	off_regexes, off_rules, off_pairsets, off_pks;
+	// pair tables that get bit rows over the tile in the kernel (RowEnds, rm_scan_hip.hip): those
+	// of the Watson-Crick helices and 4-plex outer helices that head a search level, first element's first
+	int32_t	n_rowsets;
+	int8_t	rowset_ps[ 4 ];
+	int32_t	n_regexes, n_rules, n_pairsets, n_pks, n_tups;
+	int32_t	off_regexes, off_rules, off_pairsets, off_pks, off_tups;
 	int32_t	image_bytes;
 	int8_t	searches[ RMD_MAX_ELEMS ];
 	rmd_elem_t	lctx, rctx;
@@ -139,6 +162,7 @@ struct rmd_program_t {
 	rmd_rule_t	rules[ RMD_MAX_RULES ];
 	rmd_pairset_t	pairsets[ RMD_MAX_PS ];
 	rmd_pk_t	pks[ RMD_MAX_PK ];
+	rmd_tup_t	tups[ RMD_MAX_TUP ];
 };
 
 #ifndef RMD_HD
@@ -160,6 +184,11 @@ RMD_HD const rmd_pairset_t *rmd_pairsets( const rmd_program_t *P )
 RMD_HD const rmd_pk_t *rmd_pks( const rmd_program_t *P )
 {
 	return reinterpret_cast<const rmd_pk_t *>( reinterpret_cast<const char *>( P ) + P->off_pks );
+}
+
+RMD_HD const rmd_tup_t *rmd_tups( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rmd_tup_t *>( reinterpret_cast<const char *>( P ) + P->off_tups );
 }
 
 // Build the device form; returns 0 or -1 with a message (descriptor outside

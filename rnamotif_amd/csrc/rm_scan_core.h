@@ -91,6 +91,15 @@ RMD_FN int rmd_ctz64( uint64_t x )
 #endif
 }
 
+RMD_FN int rmd_clz64( uint64_t x )	// x != 0
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+	return __clzll( ( long long )x );
+#else
+	return __builtin_clzll( x );
+#endif
+}
+
 // ---------------------------------------------------------------- seq= constraints
 // step() semantics (regexp.c:389-664) as a set-of-positions automaton: after each
 // base, `act` holds the pattern positions that just consumed it.
@@ -865,6 +874,7 @@ struct rmd_gen_t {
 	int32_t	hi0, lo0;	// first level: end position of rank 0, lowest end position allowed
 	int32_t	rank, order;
 	int32_t	pretested;	// the item is one end position that already passed the first-pairs test
+	int32_t	wend;		// last position of the item's window (relative)
 };
 
 // find_minlen()/find_maxlen() over range q of improper helix pk, find_motif.c:642-665
@@ -905,6 +915,7 @@ RMD_FN int rmd_gen_begin( const rmd_program_t *P, GR &gr, rmd_gen_t &st, int sze
 	rmd_grec_t	r;
 	r.zero = 0;
 	r.osd = int16_t( rmd_imin( szero + P->w_winsize - 1, slen - 1 ) - szero );
+	st.wend = r.osd;
 	r.sd = r.a = r.c = 0;
 	r.hl = r.ph = 0;
 	gr.set( 0, r );
@@ -923,25 +934,88 @@ RMD_FN int rmd_gen_begin( const rmd_program_t *P, GR &gr, rmd_gen_t &st, int sze
 	return 0;
 }
 
+// A level pins the window of a later level (start and/or end, relative to z; RMD_NOPIN: not this
+// one).  If an ss heads that level, what its anchored seq= demands there can be tested at once
+// instead of after every level in between: the reference's chk_seq() on the final string
+// (find_ss :346-351) can only succeed if these hold, so an alternative dropped here produces no
+// candidate there (pk1.descr: the gaaa loop closed by the first helix' 3' strand).
+#define RMD_NOPIN	( -0x7fff )
+// limit: last position the level's window can reach (its end if known, else the item's)
+RMD_FN bool rmd_pin_ok( const rmd_program_t *P, const rmd_seq_t &sq, int z, int level, int zero, int osd, int limit )
+{
+	const rmd_elem_t	&e = P->elems[ P->searches[ level ] ];
+	if( e.type != RMA_T_SS )
+		return true;
+	if( zero != RMD_NOPIN && e.pin_start ){
+		if( zero + e.minlen - 1 > limit || !rmd_prefix_ok( P, e, sq, z + zero ) )
+			return false;
+	}
+	if( osd != RMD_NOPIN && e.pin_end_n > 0 ){
+		const int	n = e.pin_end_n;
+		int	mm = 0;
+		if( osd - n + 1 < 0 || !rmd_chk_seq( P, e, sq, z + osd - n + 1, n, &mm ) )
+			return false;
+	}
+	return true;
+}
+
+// A caller may know a faster way to find the 3' ends that can start a Watson-Crick helix (the
+// kernel does, from bit vectors over the tile): ends( stp, s5, top, lo, &mask ) sets bit i of
+// mask for every end position top-63+i >= lo (absolute positions) at which the first minlen
+// pairs of helix stp with its 5' end at s5 stay within the mispair limit -- a superset of the
+// ends where match_wchlx() finds a candidate -- and returns false when it cannot tell.
+struct rmd_no_ends_t {
+	RMD_FN_MEMBER bool	ends( const rmd_elem_t &, int, int, int, uint64_t * ) const { return false; }
+};
+
+// Skip the 3' ends e, lo <= e <= *top (relative to z), at which a helix from s5 cannot start.
+// Returns with *top at the next end worth a full match, or below lo.
+template< class Accel >
+RMD_FN void rmd_gen_skip_ends( const rmd_program_t *P, const rmd_seq_t &sq, const rmd_elem_t &stp, const Accel &accel,
+	int z, int s5, int i_minl, int lo, int *top )
+{
+	int	e = *top;
+	while( e >= lo ){
+		uint64_t	m;
+		if( accel.ends( stp, z + s5, z + e, z + lo, &m ) ){
+			if( m != 0 ){
+				e -= rmd_clz64( m );	// the highest end position that passes (bit i: end e-63+i)
+				break;
+			}
+			e -= 64;
+			continue;
+		}
+		if( rmd_quick_wchlx( P, stp, sq, z + s5, z + e, rmd_s3lim( s5, e, i_minl, stp.maxlen ) + z ) )
+			break;
+		e--;
+	}
+	*top = e;
+}
+
 // Next end position of level k (find_motif :273-280): false when there is none left.
-template< class GR >
+template< class GR, class Accel >
 RMD_FN bool rmd_gen_next_sd( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
-	const rmd_elem_t &stp, rmd_grec_t &r, int *cur )
+	const rmd_elem_t &stp, rmd_grec_t &r, int *cur, const Accel &accel )
 {
 	const int	z = st.szero;
 	int	lo = stp.loop ? r.zero + stp.minglen - 1 : r.osd;
 	if( k == 0 && st.lo0 > lo )
 		lo = st.lo0;
-	if( stp.quick && !( k == 0 && st.pretested ) ){
-		// end positions whose first base pairs cannot start this helix are skipped at once: they
-		// have no effect that outlives the iteration (find_motif.c:273-280, 1010-1021)
-		while( r.sd >= lo && !rmd_quick_wchlx( P, stp, sq, z + r.zero, z + r.sd,
-			rmd_s3lim( r.zero, r.sd, stp.q_iminl, stp.maxlen ) + z ) )
-			r.sd--;
+	for( ; ; ){
+		if( stp.quick && !( k == 0 && st.pretested ) ){
+			// end positions whose first base pairs cannot start this helix are skipped at once: they
+			// have no effect that outlives the iteration (find_motif.c:273-280, 1010-1021)
+			int	e = r.sd;
+			rmd_gen_skip_ends( P, sq, stp, accel, z, r.zero, stp.q_iminl, lo, &e );
+			r.sd = int16_t( e < lo ? lo - 1 : e );
+		}
+		if( r.sd < lo )
+			return false;
+		*cur = r.sd--;
+		// an end position after which the next group's anchored seq= cannot start leads nowhere
+		if( !stp.loop || stp.next_s < 0 || rmd_pin_ok( P, sq, z, stp.next_s, *cur + 1, RMD_NOPIN, r.osd ) )
+			break;
 	}
-	if( r.sd < lo )
-		return false;
-	*cur = r.sd--;
 	if( stp.loop ){
 		if( k == 0 ){
 			st.rank = st.hi0 - *cur;
@@ -955,12 +1029,12 @@ RMD_FN bool rmd_gen_next_sd( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 
 // Advance level k to its next alternative: true with the alternative recorded in r and the
 // windows of the levels it opens set, false when the level is exhausted.
-template< class GR >
+template< class GR, class Accel >
 RMD_FN bool rmd_gen_ss( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
-	const rmd_elem_t &stp, rmd_grec_t &r )		// find_ss :332
+	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_ss :332
 {
 	r.ph = 0;
-	for( int cur; rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ); ){
+	for( int cur; rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ); ){
 		const int	len = cur - r.zero + 1;
 		if( len < stp.minlen || len > stp.maxlen )
 			continue;
@@ -975,9 +1049,9 @@ RMD_FN bool rmd_gen_ss( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd
 	return false;
 }
 
-template< class GR >
+template< class GR, class Accel >
 RMD_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
-	const rmd_elem_t &stp, rmd_grec_t &r )		// find_wchlx :400
+	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_wchlx :400
 {
 	const int	z = st.szero, d = P->searches[ k ];
 	uint64_t	cand = 0, mis = 0;
@@ -991,7 +1065,7 @@ RMD_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const 
 	}
 	for( ; ; ){
 		if( cand == 0 ){
-			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ) )
 				return false;
 			mm5 = mm3 = 0;
 			if( !rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
@@ -1004,6 +1078,8 @@ RMD_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const 
 		cand &= cand - 1;
 		if( cur - r.zero - 2 * hl + 1 > stp.maxilen )
 			continue;
+		if( !rmd_pin_ok( P, sq, z, stp.inner_s, r.zero + hl, cur - hl, cur - hl ) )
+			continue;
 		r.hl = uint8_t( hl );
 		r.ph = 1;
 		gr.set_window( stp.inner_s, r.zero + hl, cur - hl );
@@ -1013,15 +1089,28 @@ RMD_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const 
 
 // Improper helix: find_pknot :465, find_pknot5 :495, find_pknot3 :530.
 // Phases: 1 next 5' start, 2 next 3' end, 3 next helix length at (s5, s3).
-template< class GR >
+// The knot's second helix must leave interiors of admissible length on both sides of the first
+// helix' 3' strand (the hlx == 2 test, :613-627).  The reference tests that per matched length;
+// here the same inequalities bound the 5' starts, 3' ends and lengths that are tried at all.
+template< class GR, class Accel >
 RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
-	const rmd_elem_t &stp, rmd_grec_t &r )
+	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )
 {
 	const int	z = st.szero, d = P->searches[ k ], d3 = stp.mates[ 0 ];
 	const rmd_pk_t	&pk = rmd_pks( P )[ stp.pk ];
 	uint64_t	cand = 0, mis = 0;
 	int	cur = r.sd + 1;			// end position in use (ph != 0)
 	int	i_minl = 0, i_maxl, l_s5 = 0, l_s3 = 0;
+	int	iL_last = 0, iR_last = 0, iL_minl = 0, iL_maxl = 0, iR_minl = 0, iR_maxl = 0;	// second helix, :571-598
+	int	hlo = stp.minlen, hhi = stp.maxlen;	// lengths the interiors allow at the 5' start in use
+	if( pk.hlx2 ){
+		const rmd_grec_t	h1 = gr.get( pk.lvl[ 0 ] );
+		const int	s3_h1 = h1.c + 1;
+		iL_last = s3_h1 - h1.hl;
+		iR_last = s3_h1 + 1;
+		rmd_pk_len( pk, gr, RMD_PK_IL, &iL_minl, &iL_maxl );
+		rmd_pk_len( pk, gr, RMD_PK_IR, &iR_minl, &iR_maxl );
+	}
 	// the loop limits are functions of the helices matched above this level: recomputed on resume
 	auto s5_limits = [ & ]( int *f_s5 ) -> bool {		// find_pknot5 :510-522
 		int	p_minl, p_maxl, r_minl, r_maxl;
@@ -1043,7 +1132,25 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 			return false;
 		*f_s3 = cur - s_minl;
 		l_s3 = cur - rmd_imin( slen3 - g_minl, s_maxl );
+		if( pk.hlx2 ){
+			// iL = iL_last - ( s5 + hl - 1 ) in [ iL_minl, iL_maxl ] bounds hl; with it
+			// iR = ( s3 - hl + 1 ) - iR_last in [ iR_minl, iR_maxl ] bounds s3
+			hlo = rmd_imax( stp.minlen, iL_last - s5 + 1 - iL_maxl );
+			hhi = rmd_imin( stp.maxlen, iL_last - s5 + 1 - iL_minl );
+			if( hlo > hhi )
+				return false;
+			*f_s3 = rmd_imin( *f_s3, hhi - 1 + iR_last + iR_maxl );
+			l_s3 = rmd_imax( l_s3, hlo - 1 + iR_last + iR_minl );
+		}
 		return true;
+	};
+	// lengths hlo .. hhi of a candidate set
+	auto clip = [ & ]( uint64_t c ) -> uint64_t {
+		if( hlo > 0 )
+			c &= ~( ( 1ull << hlo ) - 1 );
+		if( hhi < 63 )
+			c &= ( 2ull << hhi ) - 1;
+		return c;
 	};
 	{
 		// back at the level: the limits it was left with
@@ -1056,12 +1163,12 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 			const int	s5 = r.a - 1, s3 = r.c + 1;
 			int	mm5 = 0, mm3 = 0;
 			rmd_match_wchlx_mm( P, sq, d, d3, z + s5, z + s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 );
-			cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+			cand = r.hl >= 63 ? 0 : clip( cand ) & ~( ( 2ull << r.hl ) - 1 );
 		}
 	}
 	for( ; ; ){
 		if( r.ph == 0 ){
-			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ) )
 				return false;
 			if( stp.scope == 0 ){
 				// the other helices of the knot start from the knot's window, :476-487
@@ -1086,24 +1193,31 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 			int	f_s3;
 			if( !s3_limits( s5, &f_s3 ) )
 				continue;
+			if( pk.w_osd5 >= 0 && !rmd_pin_ok( P, sq, z, pk.w_osd5, RMD_NOPIN, s5 - 1, s5 - 1 ) )
+				continue;
 			r.c = int16_t( f_s3 );
 			r.ph = 2;
 		}
 		if( r.ph == 2 ){		// next 3' end, find_pknot3 :600
 			const int	s5 = r.a - 1;
 			// 3' ends whose first pairs cannot start the helix change nothing: skip them
-			while( r.c >= l_s3 && !rmd_quick_wchlx( P, stp, sq, z + s5, z + r.c,
-				rmd_s3lim( s5, r.c, i_minl, stp.maxlen ) + z ) )
-				r.c--;
+			{
+				int	e = r.c;
+				rmd_gen_skip_ends( P, sq, stp, accel, z, s5, i_minl, l_s3, &e );
+				r.c = int16_t( e < l_s3 ? l_s3 - 1 : e );
+			}
 			if( r.c < l_s3 ){
 				r.ph = 1;
 				continue;
 			}
 			const int	s3 = r.c--;
+			if( pk.w_zero3 >= 0 && !rmd_pin_ok( P, sq, z, pk.w_zero3, s3 + 1, RMD_NOPIN, st.wend ) )
+				continue;
 			int	mm5 = 0, mm3 = 0;
 			if( !rmd_match_wchlx_mm( P, sq, d, d3, z + s5, z + s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ) + z,
 				&cand, &mis, &mm5, &mm3 ) )
 				continue;
+			cand = clip( cand );
 			r.ph = 3;
 		}
 		// ph == 3: next helix length at (s5, s3), find_pknot3 :607
@@ -1117,17 +1231,16 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 				cand = 0;	// break: longer helices only get worse
 				break;
 			}
-			if( pk.hlx2 ){		// :571-627
-				const rmd_grec_t	h1 = gr.get( pk.lvl[ 0 ] );
-				const int	s3_h1 = h1.c + 1;
-				const int	iL_last = s3_h1 - h1.hl, iR_last = s3_h1 + 1;
-				int	iL_minl, iL_maxl, iR_minl, iR_maxl;
-				rmd_pk_len( pk, gr, RMD_PK_IL, &iL_minl, &iL_maxl );
-				rmd_pk_len( pk, gr, RMD_PK_IR, &iR_minl, &iR_maxl );
+			if( pk.hlx2 ){		// :613-627
 				const int	il = iL_last - ( s5 + hl - 1 ), ir = ( s3 - hl + 1 ) - iR_last;
 				if( il < iL_minl || il > iL_maxl || ir < iR_minl || ir > iR_maxl )
 					continue;
 			}
+			// upd_pksearches(), :667: the interiors this choice pins
+			if( pk.w_zero5 >= 0 && !rmd_pin_ok( P, sq, z, pk.w_zero5, s5 + hl, RMD_NOPIN, st.wend ) )
+				continue;
+			if( pk.w_osd3 >= 0 && !rmd_pin_ok( P, sq, z, pk.w_osd3, RMD_NOPIN, s3 - hl, s3 - hl ) )
+				continue;
 			found = true;
 			break;
 		}
@@ -1136,7 +1249,6 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 			continue;
 		}
 		r.hl = uint8_t( hl );
-		// upd_pksearches(), :667
 		if( pk.w_osd5 >= 0 )
 			gr.set_osd( pk.w_osd5, s5 - 1 );
 		if( pk.w_zero5 >= 0 )
@@ -1149,18 +1261,20 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 	}
 }
 
-template< class GR >
+template< class GR, class Accel >
 RMD_COLD bool rmd_gen_phlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
-	const rmd_elem_t &stp, rmd_grec_t &r )		// find_phlx :703
+	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_phlx :703
 {
 	const int	z = st.szero, d = P->searches[ k ];
 	r.ph = 0;
-	for( int cur; rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ); ){
+	for( int cur; rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ); ){
 		int	s5hi, s5lo, hlen, n_mpr, mm5 = 0, mm3 = 0;
 		rmd_phlx_bounds( z + r.zero, cur - r.zero + 1, stp.minlen, stp.maxlen, stp.minilen, stp.maxilen, &s5hi, &s5lo );
 		if( !rmd_match_phlx( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur, s5hi, s5lo, &hlen, &n_mpr, &mm5, &mm3 ) )
 			continue;
 		if( cur - r.zero - 2 * hlen + 1 > stp.maxilen )
+			continue;
+		if( !rmd_pin_ok( P, sq, z, stp.inner_s, r.zero + hlen, cur - hlen, cur - hlen ) )
 			continue;
 		r.hl = uint8_t( hlen );
 		r.ph = 1;
@@ -1170,16 +1284,16 @@ RMD_COLD bool rmd_gen_phlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 	return false;
 }
 
-template< class GR >
+template< class GR, class Accel >
 RMD_COLD bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
-	const rmd_elem_t &stp, rmd_grec_t &r )		// find_triplex :763
+	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_triplex :763
 {
 	const int	z = st.szero, d = P->searches[ k ], d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
 	const rmd_elem_t	&stp1 = P->elems[ d1 ];
 	int	cur = r.sd + 1;
 	for( ; ; ){
 		if( r.ph == 0 ){
-			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ) )
 				return false;
 			int	s5hi, s5lo, hlen, n_mpr, mm5 = 0, mm3 = 0;
 			rmd_phlx_bounds( z + r.zero, cur - r.zero + 1, stp.minlen, stp.maxlen, stp.minilen + stp1.minilen,
@@ -1193,14 +1307,24 @@ RMD_COLD bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 			r.ph = 1;
 		}
 		const int	hlen = r.hl, last = r.zero + 2 * hlen + stp.minilen - 1;
+		// middle strand ends whose base cannot complete the first triple are passed over
+		// (match_triplex :1198-1206 returns at once when the 5' end must be paired)
+		unsigned	m2 = 0x1f;
+		if( ( stp.ends & RMA_5PAIRED ) && stp.tup >= 0 )
+			m2 = rmd_tups( P )[ stp.tup ].t2[ rmd_code( sq, z + r.zero ) * 5 + rmd_code( sq, z + cur - hlen + 1 ) ];
 		while( r.a >= last ){
 			const int	s = r.a--;
+			if( !( ( m2 >> rmd_code( sq, z + s ) ) & 1 ) )
+				continue;
 			int	n_mpr, mm1 = 0;
 			if( !rmd_match_triplex( P, sq, d, d1, z + r.zero, z + s, z + cur, hlen, &n_mpr, &mm1 ) )
 				continue;
 			if( s - 2 * hlen - r.zero + 1 > stp.maxilen )
 				continue;
 			if( cur - hlen - s > stp1.maxilen )
+				continue;
+			if( !rmd_pin_ok( P, sq, z, stp.inner_s, r.zero + hlen, s - hlen, s - hlen ) ||
+				!rmd_pin_ok( P, sq, z, stp1.inner_s, s + 1, cur - hlen, cur - hlen ) )
 				continue;
 			gr.set_window( stp.inner_s, r.zero + hlen, s - hlen );
 			gr.set_window( stp1.inner_s, s + 1, cur - hlen );
@@ -1211,9 +1335,9 @@ RMD_COLD bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 }
 
 // Phases: 1 next length of the outer helix, 2 next (s1, s2) of the inner strands.
-template< class GR >
+template< class GR, class Accel >
 RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
-	const rmd_elem_t &stp, rmd_grec_t &r )		// find_4plex :851, find_4plex_inner :902
+	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_4plex :851, find_4plex_inner :902
 {
 	const int	z = st.szero, d = P->searches[ k ];
 	const int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
@@ -1224,7 +1348,7 @@ RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 	bool	have_cand = false;		// cand holds the outer helix' lengths beyond r.hl
 	for( ; ; ){
 		if( r.ph == 0 ){
-			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur ) )
+			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ) )
 				return false;
 			int	mm5 = 0, mm3 = 0;
 			if( !rmd_match_wchlx_mm( P, sq, d, d3, z + r.zero, z + cur, rmd_s3lim( r.zero, cur, i_minl, stp.maxlen ) + z,
@@ -1256,14 +1380,23 @@ RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 		// ph == 2: find_4plex_inner :902, s1 upwards, s2 downwards
 		const int	hl = r.hl;
 		const int	s1lim = cur - 3 * hl - stp2.minilen - stp1.minilen;
+		// (s1, s2) whose bases cannot complete the first quad are passed over (match_4plex
+		// :1249-1257 returns at once when the 5' end must be paired)
+		const bool	prune = ( stp1.ends & RMA_5PAIRED ) && stp.tup >= 0;
+		const rmd_tup_t	&tup = rmd_tups( P )[ prune ? stp.tup : 0 ];
+		const int	b14 = rmd_code( sq, z + r.zero + hl - 1 ) * 5 + rmd_code( sq, z + cur - hl + 1 );
+		const unsigned	m2 = prune ? tup.q2[ b14 ] : 0x1fu;
 		while( r.a <= s1lim ){
 			const int	s1 = r.a;
-			if( r.c < s1 + 2 * hl + stp1.minilen ){
+			const int	b2 = rmd_code( sq, z + s1 );
+			if( r.c < s1 + 2 * hl + stp1.minilen || !( ( m2 >> b2 ) & 1 ) ){
 				r.a++;
 				r.c = int16_t( cur - hl - stp2.minilen );
 				continue;
 			}
 			const int	s2 = r.c--;
+			if( prune && !( ( tup.q3[ ( b14 / 5 * 5 + b2 ) * 5 + b14 % 5 ] >> rmd_code( sq, z + s2 ) ) & 1 ) )
+				continue;
 			int	n_mpr, mm1 = 0, mm2 = 0;
 			if( !rmd_match_4plex( P, sq, d1, d2, z + r.zero, z + s1, z + s2, z + cur, hl, &n_mpr, &mm1, &mm2 ) )
 				continue;
@@ -1272,6 +1405,10 @@ RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 			if( s2 - s1 - 2 * hl + 1 > stp1.maxilen )
 				continue;
 			if( cur - s2 - hl + 1 > stp2.maxilen )
+				continue;
+			if( !rmd_pin_ok( P, sq, z, stp.inner_s, r.zero + hl, s1 - 1, s1 - 1 ) ||
+				!rmd_pin_ok( P, sq, z, stp1.inner_s, s1 + hl, s2 - hl, s2 - hl ) ||
+				!rmd_pin_ok( P, sq, z, stp2.inner_s, s2 + 1, cur - hl, cur - hl ) )
 				continue;
 			gr.set_window( stp.inner_s, r.zero + hl, s1 - 1 );
 			gr.set_window( stp1.inner_s, s1 + hl, s2 - hl );
@@ -1403,27 +1540,28 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 }
 
 // One transition at level k; returns the next level, -1 when the item is done.
-template< class GR, class Sink >
-RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k, rmd_lane_t *L, Sink &sink )
+template< class GR, class Sink, class Accel = rmd_no_ends_t >
+RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k, rmd_lane_t *L, Sink &sink,
+	const Accel &accel = Accel() )
 {
 	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
 	rmd_grec_t	r = gr.get( k );
 	bool	ok;
 	switch( stp.type ){
 	case RMA_T_SS :
-		ok = rmd_gen_ss( P, gr, st, sq, k, stp, r );
+		ok = rmd_gen_ss( P, gr, st, sq, k, stp, r, accel );
 		break;
 	case RMA_T_H5 :
-		ok = stp.proper ? rmd_gen_wchlx( P, gr, st, sq, k, stp, r ) : rmd_gen_pknot( P, gr, st, sq, k, stp, r );
+		ok = stp.proper ? rmd_gen_wchlx( P, gr, st, sq, k, stp, r, accel ) : rmd_gen_pknot( P, gr, st, sq, k, stp, r, accel );
 		break;
 	case RMA_T_P5 :
-		ok = rmd_gen_phlx( P, gr, st, sq, k, stp, r );
+		ok = rmd_gen_phlx( P, gr, st, sq, k, stp, r, accel );
 		break;
 	case RMA_T_T1 :
-		ok = rmd_gen_triplex( P, gr, st, sq, k, stp, r );
+		ok = rmd_gen_triplex( P, gr, st, sq, k, stp, r, accel );
 		break;
 	case RMA_T_Q1 :
-		ok = rmd_gen_4plex( P, gr, st, sq, k, stp, r );
+		ok = rmd_gen_4plex( P, gr, st, sq, k, stp, r, accel );
 		break;
 	default :
 		ok = false;
@@ -1442,12 +1580,12 @@ RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rm
 
 // The search for one start position (one iteration of RM_find_motif's loops,
 // find_motif.c:184-205), restricted to ranks r0 .. r0+cnt-1 of the first element.
-template< class GR, class Sink >
+template< class GR, class Sink, class Accel = rmd_no_ends_t >
 RMD_FN void rmd_gen_position( const rmd_program_t *P, GR &gr, rmd_lane_t *L, const rmd_seq_t &sq,
-	int szero, int slen, int r0, int cnt, Sink &sink )
+	int szero, int slen, int r0, int cnt, Sink &sink, const Accel &accel = Accel() )
 {
 	rmd_gen_t	st;
 	int	k = rmd_gen_begin( P, gr, st, szero, slen, r0, cnt );
 	while( k >= 0 )
-		k = rmd_gen_step( P, gr, st, sq, k, L, sink );
+		k = rmd_gen_step( P, gr, st, sq, k, L, sink, accel );
 }

@@ -218,6 +218,65 @@ struct TailAccel {
 	}
 };
 
+// Pair rows of one pair table over a tile: rows5[ b * pb_words ] has a bit per tile position (64
+// pad bits in front) whose base can be the 3' partner of 5' base b.  End positions w0 .. w0+63 of
+// a helix whose 5' strand starts at s5: bit i of the result is set when the first hl0 pairs of
+// (s5, w0+i) hold with at most lim mispairs (and, with ends5, the first pair itself holds) --
+// match_wchlx's rule for reaching length minlen, find_motif.c:1010-1033,1065-1080; positions
+// below lo are cleared.
+__device__ inline unsigned long long rows_win( const unsigned long long *rows5, int pb_words, const uint8_t *tile, int p_lo,
+	int hl0, int lim, bool ends5, int s5, int w0, int lo )
+{
+	unsigned long long	W;
+	if( lim == 0 ){
+		// no mispair allowed: a plain AND of the shifted rows, done as soon as no end position is left
+		W = ~0ull;
+		for( int h = 0; h < hl0 && W; h++ ){
+			const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector
+			W &= qq >= 0 ? bits64( rows5 + tile[ s5 + h - p_lo ] * pb_words, qq ) : 0ull;
+		}
+	}else{
+		unsigned long long	c1 = 0, c2 = 0, c3 = 0, c4 = 0, first = 0;	// >= 1/2/3/4 mispairs
+		for( int h = 0; h < hl0; h++ ){
+			const int	qq = w0 - h - p_lo + 64;
+			const unsigned long long	mis = ~( qq >= 0 ? bits64( rows5 + tile[ s5 + h - p_lo ] * pb_words, qq ) : 0ull );
+			if( h == 0 )
+				first = mis;
+			c4 |= c3 & mis;
+			c3 |= c2 & mis;
+			c2 |= c1 & mis;
+			c1 |= mis;
+		}
+		W = ~( lim == 1 ? c2 : lim == 2 ? c3 : c4 );
+		if( ends5 )
+			W &= ~first;
+	}
+	const int	imin = lo - w0;
+	if( imin > 0 )
+		W = imin >= 64 ? 0 : W & ( ~0ull << imin );
+	return W;
+}
+
+// rmd_gen_skip_ends()'s accelerator: the 3' ends that can start helix stp, from the pair rows of
+// its pair table (rmd_elem_t::rows names the row set; -1: none, the core tests end by end)
+struct RowEnds {
+	const unsigned long long	*rows;		// row set 0; set j at rows + 5 * j * pb_words
+	const uint8_t	*tile;
+	int	pb_words, p_lo, vec_bits;
+	__device__ inline bool	ends( const rmd_elem_t &stp, int s5, int top, int lo, uint64_t *mask ) const
+	{
+		if( stp.rows < 0 )
+			return false;
+		const int	w0 = top - 63, q_hi = w0 - p_lo + 64;
+		if( q_hi + 96 > vec_bits || s5 < p_lo )		// (bits64 reads three dwords from its first bit)
+			return false;
+		const int	lim = ( stp.ends & RMA_5PAIRED ) ? stp.mplim : ( stp.mplim > 1 ? stp.mplim : 1 );
+		*mask = rows_win( rows + 5 * stp.rows * pb_words, pb_words, tile, p_lo, stp.minlen, lim,
+			( stp.ends & RMA_5PAIRED ) != 0, s5, w0, lo );
+		return true;
+	}
+};
+
 // ---------------------------------------------------------------- search kernel
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
@@ -279,13 +338,17 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// first helix of a pseudoknot whose 5' strand starts at the start position
 	const bool	pk0 = e0.type == RMA_T_H5 && !e0.proper && e0.scope == 0 && !( dbg & 4 ) &&
 		e0.mplim <= 3 && e0.minlen >= 1;
-	const bool	bitpar = ( ( quick && !( dbg & 4 ) ) || pk0 ) && e0.mplim <= 3 && e0.minlen >= 1;
+	const bool	bitpar = ( ( quick && !( dbg & 4 ) ) || pk0 ) && e0.mplim <= 3 && e0.minlen >= 1 && e0.rows == 0;
 	const unsigned	e0_mat2 = e0.pairset >= 0 ? rmd_pairsets( P )[ e0.pairset ].mat2 : 0;
 	const bool	e0_at_szero = e0.type == RMA_T_P5 || e0.type == RMA_T_T1 || e0.type == RMA_T_Q1 ||
 		( e0.type == RMA_T_H5 && ( e0.proper || e0.scope == 0 ) );
 	const int	pb_words = ( tile_bytes + 63 ) / 64 + 3;
+	// bit vectors of a slot: where the best literal occurs, then five pair rows per row set (the lean
+	// instance keeps one set, the first element's; the general one a set per pair table its helices use)
+	const int	n_rs = LEAN ? 1 : P->n_rowsets;
+	const int	n_vec = 1 + 5 * n_rs;
 	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
-	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * 6 * pb_words );
+	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
 	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
 	LdsGRecs<BLOCK>	gr{ lean_lo + threadIdx.x };		// (the general instance's records take the same place)
@@ -349,7 +412,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		// what pass B needs of the tile (G > 1: of the last slot; pass B reloads per item)
 		int	seq = 0, slen = 0, z0 = 0, p_lo = 0, vec_words = 0;
 		uint8_t	*tile = tile0;
-		unsigned long long	*pb = pb0;
+		unsigned long long	*pb = pb0 + pb_words;
 		rmd_seq_t	sq{ tile0, 0 };
 		DevSink	sink{ hb, 0, 0, P->hit_stride };
 		const int	lane_id = tid & 63;
@@ -362,8 +425,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		seq = G > 1 ? ( live ? db.tile_seq[ tt ] : 0 ) : s_seq;
 		slen = db.slen[ seq ];
 		tile = tile0 + size_t( slot ) * slot_bytes;
-		pb = pb0 + size_t( slot ) * 6 * pb_words;
-		unsigned long long	*const occ = pb + 5 * pb_words;	// where the best literal occurs (bit per start)
+		unsigned long long	*const occ = pb0 + size_t( slot ) * n_vec * pb_words;	// where the best literal occurs (bit per start)
+		pb = occ + pb_words;		// row set 0
 		const int64_t	off = db.base_off[ seq ];
 		const int	local = live ? int( tt - db.tile_start[ seq ] ) : 0;
 		const int	per_strand = live ? int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands ) : 1;
@@ -480,23 +543,29 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			} \
 		} }while( 0 )
 
-		if( bitpar ){
-			// Bit-parallel form for helices without mispairs: pb[ b ] has a bit per tile
-			// position that can pair with 5' base b, so "the first minlen pairs of
-			// (start, end) all pair" is an AND of minlen shifted 64-bit windows, 64 end
-			// positions at a time.
+		// Pair rows: for every row set, rows[ b ] has a bit per tile position that can pair with 5'
+		// base b (one ballot per 64 positions and row), so "the first minlen pairs of (start, end)
+		// hold" is an AND of minlen shifted 64-bit windows, 64 end positions at a time -- for the
+		// pre-filter below and for the helices of the search itself (RowEnds).
+		if( LEAN ? bitpar : n_rs > 0 ){
 			const int	n_valid = p_to - p_lo;
-			for( int base = ubase; base < vec_words * 64; base += UNIT ){
-				const int	q = base + lane_id - 64;		// one pad word in front
-				const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
-				for( int b5 = 0; b5 < 5; b5++ ){
-					const unsigned long long	m = __ballot( code < 5 && ( ( e0_mat2 >> ( b5 * 5 + code ) ) & 1 ) );
-					if( lane_id == b5 )
-						pb[ b5 * pb_words + ( base >> 6 ) ] = m;
+			for( int rs = 0; rs < n_rs; rs++ ){
+				const unsigned	mat2 = rmd_pairsets( P )[ P->rowset_ps[ rs ] ].mat2;
+				unsigned long long	*const rows = pb + 5 * rs * pb_words;
+				for( int base = ubase; base < vec_words * 64; base += UNIT ){
+					const int	q = base + lane_id - 64;		// one pad word in front
+					const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
+					for( int b5 = 0; b5 < 5; b5++ ){
+						const unsigned long long	m = __ballot( code < 5 && ( ( mat2 >> ( b5 * 5 + code ) ) & 1 ) );
+						if( lane_id == b5 )
+							rows[ b5 * pb_words + ( base >> 6 ) ] = m;
+					}
 				}
 			}
 			SLOT_SYNC();
 			PHASE( 2 );
+		}
+		if( bitpar ){
 			const int	hl0 = e0.minlen;
 			// superset of match_wchlx's rule (find_motif.c:1010-1033,1065-1080): at most mplim
 			// mispairs among the first minlen pairs; an unpaired first pair is allowed only if
@@ -504,47 +573,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			const int	lim = ( e0.ends & RMA_5PAIRED ) ? e0.mplim : ( e0.mplim > 1 ? e0.mplim : 1 );
 			// end positions top-r0-63 .. top-r0 of a helix starting at szero: bit i set when
 			// end position top-r0-63+i passes; positions below lo are cleared
+			const bool	ends5 = ( e0.ends & RMA_5PAIRED ) != 0;
 			auto	win = [ & ]( int szero, int top, int r0, int lo ) -> unsigned long long {
-				unsigned long long	c1 = 0, c2 = 0, c3 = 0, c4 = 0, first = 0;	// >= 1/2/3/4 mispairs
-				const int	w0 = top - r0 - 63;
-				if( lim == 0 ){
-					// no mispair allowed: a plain AND of the shifted rows, and done as
-					// soon as no end position is left
-					unsigned long long	W = ~0ull;
-					for( int h = 0; h < hl0 && W; h++ ){
-						const int	qq = w0 - h - p_lo + 64;
-						unsigned long long	ph = 0;
-						if( qq >= 0 ){
-							ph = bits64( pb + rmd_code( sq, szero + h ) * pb_words, qq );
-						}
-						W &= ph;
-					}
-					const int	imin = lo - w0;
-					if( imin > 0 )
-						W = imin >= 64 ? 0 : W & ( ~0ull << imin );
-					return W;
-				}
-				for( int h = 0; h < hl0; h++ ){
-					const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector
-					unsigned long long	ph = 0;
-					if( qq >= 0 ){
-						ph = bits64( pb + rmd_code( sq, szero + h ) * pb_words, qq );
-					}
-					const unsigned long long	mis = ~ph;
-					if( h == 0 )
-						first = mis;
-					c4 |= c3 & mis;
-					c3 |= c2 & mis;
-					c2 |= c1 & mis;
-					c1 |= mis;
-				}
-				unsigned long long	W = ~( lim == 0 ? c1 : lim == 1 ? c2 : lim == 2 ? c3 : c4 );
-				if( e0.ends & RMA_5PAIRED )
-					W &= ~first;
-				const int	imin = lo - w0;
-				if( imin > 0 )
-					W = imin >= 64 ? 0 : W & ( ~0ull << imin );
-				return W;
+				return rows_win( pb, pb_words, tile, p_lo, hl0, lim, ends5, szero, top - r0 - 63, lo );
 			};
 			for( int j = 0; j < n_pos; j += UNIT ){
 				const int	rel = j + utid;
@@ -707,7 +738,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 								z0 = c[ 3 ];
 								p_lo = c[ 4 ];
 								tile = tile0 + size_t( sl ) * slot_bytes;
-								pb = pb0 + size_t( sl ) * 6 * pb_words;
+								pb = pb0 + ( size_t( sl ) * n_vec + 1 ) * pb_words;
 								sq = rmd_seq_t{ tile, p_lo };
 								sink.seq = c[ 0 ];
 								sink.comp = c[ 1 ];
@@ -749,6 +780,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		}else{
 			// every element type: 12 bytes of search state per level, in LDS (rmd_grec_t)
 			rmd_gen_t	st;
+			const RowEnds	ends{ pb, tile, pb_words, p_lo, ( dbg & 64 ) ? 0 : vec_words * 64 };	// (bit 64: end by end, no rows)
 			for( ; ; ){
 				const unsigned long long	want = __ballot( k < 0 && !dry );
 				if( want ){
@@ -771,7 +803,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( __ballot( k >= 0 ) == 0 )
 					break;
 				if( k >= 0 )
-					k = rmd_gen_step( P, gr, st, sq, k, &lane, sink );
+					k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends );
 			}
 		}
 		PHASE( 4 );
@@ -913,7 +945,7 @@ extern "C" int rma_device_count( void )
 static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1 )
 {
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	const size_t	pb_bytes = 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	lds += size_t( dp.n_searches ) * 256 * ( lean ? LEAN_REC_BYTES : GEN_REC_BYTES );

@@ -62,6 +62,41 @@ struct GenRecs {
 	int	hl( int k ) const { return r[ k ].hl; }
 };
 
+// rmd_gen_skip_ends()'s accelerator as the kernel defines it (RowEnds, rm_scan_hip.hip), bit by
+// bit instead of from bit vectors: the first minlen pairs of (s5, end) within the mispair limit
+struct HostEnds {
+	const rmd_program_t	*P;
+	rmd_seq_t	sq;
+	int	slen;
+	bool	ends( const rmd_elem_t &stp, int s5, int top, int lo, uint64_t *mask ) const
+	{
+		if( stp.rows < 0 || getenv( "HOSTSIM_NOENDS" ) )
+			return false;
+		const int	lim = ( stp.ends & RMA_5PAIRED ) ? stp.mplim : ( stp.mplim > 1 ? stp.mplim : 1 );
+		uint64_t	m = 0;
+		for( int i = 0; i < 64; i++ ){
+			const int	e = top - 63 + i;
+			if( e < lo || e >= slen )
+				continue;
+			int	mis = 0;
+			bool	ok = true;
+			for( int h = 0; h < stp.minlen && ok; h++ ){
+				const bool	pr = e - h >= 0 && s5 + h < slen &&
+					rmd_paired( P, stp.pairset, rmd_code( sq, s5 + h ), rmd_code( sq, e - h ) );
+				if( !pr ){
+					mis++;
+					if( h == 0 && ( stp.ends & RMA_5PAIRED ) )
+						ok = false;
+				}
+			}
+			if( ok && mis <= lim )
+				m |= 1ull << i;
+		}
+		*mask = m;
+		return true;
+	}
+};
+
 // one work item, through the lean path when the descriptor allows it
 static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t &sq, int szero, int slen, int r0, int cnt, VecSink &sink )
 {
@@ -74,7 +109,8 @@ static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t
 	}else{
 		GenRecs	recs;
 		memset( &recs, 0x55, sizeof( recs ) );	// (windows are written before they are read: any garbage must do)
-		rmd_gen_position( dp, recs, lane, sq, szero, slen, r0, cnt, sink );
+		HostEnds	ends{ dp, sq, slen };
+		rmd_gen_position( dp, recs, lane, sq, szero, slen, r0, cnt, sink, ends );
 	}
 }
 

@@ -582,9 +582,13 @@ def _random_general_descriptor(rng):
         spec = "minlen=%d,maxlen=%d" % (a, b)
         if rng.random() < 0.2:
             spec = "len=%d" % max(1, b)
-        if rng.random() < 0.15:
-            spec += ', seq="%s"' % "".join("acgt"[int(x)] for x in rng.integers(0, 4, size=2))
-            if rng.random() < 0.3:
+        if rng.random() < 0.2:
+            pat = "".join("acgt"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(1, 3))))
+            form = rng.random()     # plain, ^anchored, anchored$, ^both$ (the early tests of pinned windows)
+            if form >= 0.4:
+                pat = ("^" if form < 0.6 or form >= 0.8 else "") + pat + ("$" if form >= 0.6 else "")
+            spec += ', seq="%s"' % pat
+            if rng.random() < 0.25:
                 spec += ",mismatch=1"
         lines.append("\t" * indent + "ss(%s)" % spec)
 
