@@ -1,5 +1,6 @@
 #!/bin/bash
-# profiles/collect.sh LABEL -- on the GPU box: the default bench.py workload under rocprofv3,
+# profiles/collect.sh LABEL [bench.py flags] -- on the GPU box: the default bench.py workload (or the
+# one the flags name, e.g. --descr tests/golden/test/pk1.descr) under rocprofv3,
 # one kernel-trace + stats run and separate PMC passes (never combined with other trace
 # domains), written under gpurun_out/prof_LABEL; profiles/summarize.py condenses them.
 #   gpurun --timeout 900 -- 'bash profiles/collect.sh r1x'
@@ -7,10 +8,11 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$1
+shift
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --steps 1 --warmup 0 --cpu-bases 0"
-python3 $R/bench.py > $O/bench_plain.log 2>&1
+B="$R/bench.py --steps 1 --warmup 0 --cpu-bases 0 $*"
+python3 $R/bench.py --cpu-bases 0 $* > $O/bench_plain.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $B > $O/bench_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python3 $B > $O/bench_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python3 $B > $O/bench_write.log 2>&1

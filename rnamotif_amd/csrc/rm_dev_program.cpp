@@ -263,6 +263,29 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		if( !e.loop && re.dollar && re.fixed_len > 0 && re.fixed_len <= 63 && re.opt == 0 && re.star == 0 )
 			e.pin_end_n = int8_t( re.fixed_len );
 	}
+	// an ss that is the whole of an interior (no loop over its end, find_motif :266-272) has one
+	// alternative: the general path passes through such levels without a step of their own
+	{
+		int	back = -1;
+		for( int s = 0; s < p->n_searches; s++ ){
+			rmd_elem_t	&e = out->elems[ p->searches[ s ] ];
+			e.back_s = int8_t( back );
+			if( !( e.type == RMA_T_SS && !e.loop ) )
+				back = s;
+		}
+	}
+	// split level: the helices at the head of the search list are where most start positions die
+	{
+		int	run = 0;
+		while( run < p->n_searches && out->elems[ p->searches[ run ] ].type != RMA_T_SS )
+			run++;
+		bool	more = false;		// a level with a choice after them
+		for( int s = run; s < p->n_searches; s++ ){
+			const rmd_elem_t	&e = out->elems[ p->searches[ s ] ];
+			more = more || !( e.type == RMA_T_SS && !e.loop );
+		}
+		out->split_s = run >= 1 && run <= 4 && more ? run - 1 : -1;
+	}
 	// first-tuple masks of the triplex / 4-plex pair tables
 	int	n_tups = 0;
 	for( int d = 0; d < p->n_elems; d++ )

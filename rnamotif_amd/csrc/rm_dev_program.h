@@ -77,7 +77,9 @@ struct rmd_elem_t {
 	int8_t	pin_start;		// ^-anchored: its leading mandatory positions at the window start
 	int8_t	pin_end_n;		// > 0: the ss is its whole window and the expression is $-anchored with
 					// this fixed length: its last pin_end_n bases, once the window end is known
-	int8_t	pad2_[ 2 ];
+	int8_t	back_s;			// head of a level: the level to go back to when this one is exhausted -- the
+					// nearest one below it that has more than one alternative (-1: the item is done)
+	int8_t	pad2_[ 1 ];
 };
 
 // First-tuple masks of a triplex / 4-plex pair table: match_triplex()/match_4plex() give up at
@@ -129,6 +131,9 @@ struct rmd_program_t {
 	int32_t	n_elems, n_searches;
 	int32_t	dminlen, w_winsize;	// min( dmaxlen, windowsize )
 	int32_t	strict_helices;
+	int32_t	split_s;		// general path: alternatives of this level are handed over as continuations
+					// (rm_scan_core.h, rmd_gen_resume): the last of the helices that head the
+					// search list when levels follow it; -1: none
 	int32_t	need_init;		// some helix is improper: element state must start UNDEF
 	int32_t	lean_ok;		// every level is ss or a proper helix: 8-byte-per-level search
 	int32_t	has_lctx, has_rctx;

@@ -869,12 +869,29 @@ struct rmd_grec_t {
 	uint8_t	ph;		// generator phase (0: looking for an end position)
 };
 
+// the iterator part of a record as two words (how the kernel keeps it in LDS, and what a
+// continuation carries): next end position | first loop variable, second loop variable | helix length | phase
+RMD_FN uint32_t rmd_grec_word1( const rmd_grec_t &v ) { return uint32_t( uint16_t( v.sd ) ) | ( uint32_t( uint16_t( v.a ) ) << 16 ); }
+RMD_FN uint32_t rmd_grec_word2( const rmd_grec_t &v )
+{
+	return uint32_t( uint16_t( v.c ) ) | ( uint32_t( v.hl ) << 16 ) | ( uint32_t( v.ph ) << 24 );
+}
+RMD_FN void rmd_grec_set_words( rmd_grec_t &r, uint32_t d1, uint32_t d2 )
+{
+	r.sd = int16_t( d1 & 0xffffu );
+	r.a = int16_t( d1 >> 16 );
+	r.c = int16_t( d2 & 0xffffu );
+	r.hl = uint8_t( ( d2 >> 16 ) & 0xffu );
+	r.ph = uint8_t( d2 >> 24 );
+}
+
 struct rmd_gen_t {
 	int32_t	szero, slen;
 	int32_t	hi0, lo0;	// first level: end position of rank 0, lowest end position allowed
 	int32_t	rank, order;
 	int32_t	pretested;	// the item is one end position that already passed the first-pairs test
 	int32_t	wend;		// last position of the item's window (relative)
+	int32_t	tag;		// >= 0: what candidates carry as their order (an alternative of the split level, below)
 };
 
 // find_minlen()/find_maxlen() over range q of improper helix pk, find_motif.c:642-665
@@ -912,6 +929,7 @@ RMD_FN int rmd_gen_begin( const rmd_program_t *P, GR &gr, rmd_gen_t &st, int sze
 	st.slen = slen;
 	st.rank = -1;
 	st.order = 0;
+	st.tag = -1;
 	rmd_grec_t	r;
 	r.zero = 0;
 	r.osd = int16_t( rmd_imin( szero + P->w_winsize - 1, slen - 1 ) - szero );
@@ -1526,7 +1544,7 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 	L->slen = st.slen;
 	L->szero = z;
 	L->rank = st.rank;
-	L->order = st.order;
+	L->order = st.tag >= 0 ? st.tag : st.order;
 	L->l_mm = L->r_mm = RMD_UNDEF;
 	L->l_off = L->l_len = L->r_off = L->r_len = 0;
 	if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
@@ -1536,46 +1554,146 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 	if( !rmd_chk_sites( P, L, sq ) )
 		return;
 	sink.put( P, L, z );
-	st.order++;
+	if( st.tag < 0 )
+		st.order++;
 }
 
-// One transition at level k; returns the next level, -1 when the item is done.
-template< class GR, class Sink, class Accel = rmd_no_ends_t >
-RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k, rmd_lane_t *L, Sink &sink,
-	const Accel &accel = Accel() )
+// The next alternative of level k (find_1_motif's dispatch, :289-330)
+template< class GR, class Accel >
+RMD_FN bool rmd_gen_next( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )
 {
-	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
-	rmd_grec_t	r = gr.get( k );
-	bool	ok;
 	switch( stp.type ){
 	case RMA_T_SS :
-		ok = rmd_gen_ss( P, gr, st, sq, k, stp, r, accel );
-		break;
+		return rmd_gen_ss( P, gr, st, sq, k, stp, r, accel );
 	case RMA_T_H5 :
-		ok = stp.proper ? rmd_gen_wchlx( P, gr, st, sq, k, stp, r, accel ) : rmd_gen_pknot( P, gr, st, sq, k, stp, r, accel );
-		break;
+		return stp.proper ? rmd_gen_wchlx( P, gr, st, sq, k, stp, r, accel ) : rmd_gen_pknot( P, gr, st, sq, k, stp, r, accel );
 	case RMA_T_P5 :
-		ok = rmd_gen_phlx( P, gr, st, sq, k, stp, r, accel );
-		break;
+		return rmd_gen_phlx( P, gr, st, sq, k, stp, r, accel );
 	case RMA_T_T1 :
-		ok = rmd_gen_triplex( P, gr, st, sq, k, stp, r, accel );
-		break;
+		return rmd_gen_triplex( P, gr, st, sq, k, stp, r, accel );
 	case RMA_T_Q1 :
-		ok = rmd_gen_4plex( P, gr, st, sq, k, stp, r, accel );
-		break;
+		return rmd_gen_4plex( P, gr, st, sq, k, stp, r, accel );
 	default :
-		ok = false;
-		break;
+		return false;
 	}
-	if( !ok )
-		return k - 1;
-	gr.set_iter( k, r );
-	if( k < P->n_searches - 1 ){
-		rmd_gen_open( P, gr, k + 1 );
-		return k + 1;
+}
+
+// Down from level k through the levels that have one alternative (an ss that is the whole of an
+// interior: find_ss :332-351 on its window): the next level with a choice, n_searches when the
+// match is complete, -1 when one of them fails.
+template< class GR >
+RMD_FN int rmd_gen_descend( const rmd_program_t *P, GR &gr, const rmd_gen_t &st, const rmd_seq_t &sq, int k )
+{
+	int	j = k + 1;
+	for( ; j < P->n_searches; j++ ){
+		const rmd_elem_t	&e = P->elems[ P->searches[ j ] ];
+		if( e.type != RMA_T_SS || e.loop )
+			break;
+		rmd_grec_t	c = gr.get( j );
+		const int	len = c.osd - c.zero + 1;
+		int	mm = 0;
+		if( len < e.minlen || len > e.maxlen || ( e.re >= 0 && !rmd_chk_seq( P, e, sq, st.szero + c.zero, len, &mm ) ) )
+			return -1;
+		c.sd = int16_t( c.osd - 1 );		// (as rmd_gen_ss() leaves it: the one end position, taken)
+		c.ph = 1;
+		gr.set_iter( j, c );
 	}
-	rmd_gen_emit( P, gr, st, sq, L, sink );
-	return k;
+	return j;
+}
+
+// The search tree of an item is narrow at the top and, now and then, deep: most lanes of a wave
+// work on the first levels (the helices that head the search list) while the few that found
+// something there walk the rest alone, each on its own code path.  With a split level S =
+// rmd_program_t::split_s, an alternative of level S that survives is not walked by the lane that
+// found it: it is handed over as a continuation -- the item, and for each level 0..S the iterator
+// its generator was resumed from, which reproduces the alternative (generators are functions of
+// the records above them and the sequence) -- and walked later next to other continuations
+// (rmd_gen_resume, the kernel's second round over a tile).  Candidates then carry the number of
+// their level-S alternative within (start, rank) as their order; the lane that walks an
+// alternative emits its candidates in the reference's order, so the order of the hit buffer
+// breaks the ties and the host renumbers (rma_scan).
+struct rmd_no_split_t {
+	RMD_FN_MEMBER int	level() const { return -1; }
+	template< class GR >
+	RMD_FN_MEMBER bool	push( const rmd_gen_t &, GR &, int ) const { return false; }
+};
+
+// One transition at level k; returns the next level, -1 when the item is done.  Levels whose
+// element has a single alternative take no transition of their own: they are checked on the way
+// down (rmd_gen_descend) and skipped on the way back (rmd_elem_t::back_s), so a lane spends its
+// steps on the levels that have a choice -- and so do the lanes next to it.
+template< class GR, class Sink, class Accel = rmd_no_ends_t, class Split = rmd_no_split_t >
+RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k, rmd_lane_t *L, Sink &sink,
+	const Accel &accel = Accel(), const Split &split = Split() )
+{
+	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
+	const int	S = split.level();
+	rmd_grec_t	r = gr.get( k );
+	for( ; ; ){
+		if( S >= 0 && k <= S )
+			gr.set_before( k, r );		// what this alternative's generator is resumed from
+		if( !rmd_gen_next( P, gr, st, sq, k, stp, r, accel ) )
+			return stp.back_s;
+		gr.set_iter( k, r );
+		const int	j = rmd_gen_descend( P, gr, st, sq, k );
+		if( j < 0 )
+			continue;		// this alternative of level k leads nowhere: its next one
+		if( k == S ){
+			// an alternative of the split level: numbered, and walked by whoever takes the continuation
+			const int	alt = st.order++;
+			if( j < P->n_searches && split.push( st, gr, alt ) )
+				continue;
+			st.tag = alt;
+		}
+		if( j < P->n_searches ){
+			rmd_gen_open( P, gr, j );
+			return j;
+		}
+		rmd_gen_emit( P, gr, st, sq, L, sink );
+		return k;
+	}
+}
+
+// Take up a continuation: item (szero, r0, cnt) as rmd_gen_begin() takes it, before[ 2 * j ],
+// before[ 2 * j + 1 ] the iterator (GR's packing of rmd_grec_t's sd | a and c | hl | ph) level
+// j <= S was resumed from, alt the alternative's number.  Returns the level to go on with; the
+// continuation is finished when rmd_gen_step() comes back to a level <= S.
+template< class GR, class Accel >
+RMD_FN int rmd_gen_resume( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq,
+	int szero, int slen, int r0, int cnt, int S, const uint32_t *before, int alt, const Accel &accel )
+{
+	rmd_gen_begin( P, gr, st, szero, slen, r0, cnt );
+	for( int j = 0; j <= S; j++ ){
+		gr.set_iter_words( j, before[ 2 * j ], before[ 2 * j + 1 ] );
+		rmd_grec_t	r = gr.get( j );
+		const rmd_elem_t	&stp = P->elems[ P->searches[ j ] ];
+		if( r.ph != 0 ){
+			// resumed within an end position: what taking that end position had set up
+			// (rmd_gen_next_sd, and find_pknot :476-487 for the first helix of a knot)
+			const int	cur = r.sd + 1;
+			if( stp.loop && stp.next_s >= 0 )
+				gr.set_window( stp.next_s, cur + 1, r.osd );
+			if( stp.type == RMA_T_H5 && !stp.proper && stp.scope == 0 ){
+				const rmd_pk_t	&pk = rmd_pks( P )[ stp.pk ];
+				for( int x = 1; x < stp.n_scopes; x++ )
+					if( P->elems[ stp.scopes[ x ] ].type == RMA_T_H5 )
+						gr.set_window( pk.lvl[ x ], r.zero, cur );
+			}
+		}
+		if( !rmd_gen_next( P, gr, st, sq, j, stp, r, accel ) )
+			return -1;		// (cannot happen: the alternative was found from this very state)
+		gr.set_iter( j, r );
+		if( j < S )
+			rmd_gen_open( P, gr, j + 1 );
+	}
+	st.tag = alt;
+	st.rank = st.hi0 - ( gr.get( 0 ).sd + 1 );	// (the first level may have been resumed within an end position)
+	const int	j = rmd_gen_descend( P, gr, st, sq, S );
+	if( j < 0 || j >= P->n_searches )
+		return -1;			// (only alternatives with levels left to walk are handed over)
+	rmd_gen_open( P, gr, j );
+	return j;
 }
 
 // The search for one start position (one iteration of RM_find_motif's loops,

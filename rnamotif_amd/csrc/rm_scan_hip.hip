@@ -141,8 +141,8 @@ struct LdsGRecs {
 	}
 	__device__ inline void	set_iter( int k, rmd_grec_t v )
 	{
-		w[ ( 3 * k + 1 ) * BLOCK ] = ( uint32_t( uint16_t( v.sd ) ) ) | ( uint32_t( uint16_t( v.a ) ) << 16 );
-		w[ ( 3 * k + 2 ) * BLOCK ] = ( uint32_t( uint16_t( v.c ) ) ) | ( uint32_t( v.hl ) << 16 ) | ( uint32_t( v.ph ) << 24 );
+		w[ ( 3 * k + 1 ) * BLOCK ] = rmd_grec_word1( v );
+		w[ ( 3 * k + 2 ) * BLOCK ] = rmd_grec_word2( v );
 	}
 	__device__ inline void	set_window( int k, int zero, int osd )
 	{
@@ -164,6 +164,45 @@ struct LdsGRecs {
 		d0 = ( d0 & 0xffffu ) | ( uint32_t( osd ) << 16 );
 	}
 	__device__ inline int	hl( int k ) const { return int( ( w[ ( 3 * k + 2 ) * BLOCK ] >> 16 ) & 0xffu ); }
+	// levels up to the split level: the iterator each one's alternative was resumed from (rmd_gen_step)
+	uint32_t	*bw;
+	__device__ inline void	set_before( int k, rmd_grec_t v )
+	{
+		bw[ ( 2 * k ) * BLOCK ] = rmd_grec_word1( v );
+		bw[ ( 2 * k + 1 ) * BLOCK ] = rmd_grec_word2( v );
+	}
+	__device__ inline uint32_t	before_word( int i ) const { return bw[ i * BLOCK ]; }
+	__device__ inline void	set_iter_words( int k, uint32_t d1, uint32_t d2 )
+	{
+		w[ ( 3 * k + 1 ) * BLOCK ] = d1;
+		w[ ( 3 * k + 2 ) * BLOCK ] = d2;
+	}
+};
+
+// rmd_gen_step()'s hand-over of the alternatives of the split level: a queue of continuations in
+// LDS, walked in the tile's second round.  Entry: the work item, the alternative's number, and
+// two words per level 0..S (LdsGRecs::set_before).  A full queue refuses: the lane walks on itself.
+#define DEEP_QUEUE	512
+struct LdsSplit {
+	int	S;
+	uint32_t	*dq;
+	int	*dq_n;
+	const unsigned	*item;
+	__device__ inline int	level() const { return S; }
+	__device__ inline int	entry_words() const { return 2 + 2 * ( S + 1 ); }
+	template< class GR >
+	__device__ inline bool	push( const rmd_gen_t &, GR &gr, int alt ) const
+	{
+		const int	slot = atomicAdd( dq_n, 1 );
+		if( slot >= DEEP_QUEUE )
+			return false;
+		uint32_t	*e = dq + slot * entry_words();
+		e[ 0 ] = *item;
+		e[ 1 ] = uint32_t( alt );
+		for( int i = 0; i < 2 * ( S + 1 ); i++ )
+			e[ 2 + i ] = gr.before_word( i );
+		return true;
+	}
 };
 
 // 64 bits of a bit vector starting at bit q: three dwords through two v_alignbit_b32
@@ -310,7 +349,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	uint8_t	*const tile0 = smem + prog_bytes + qcap * sizeof( unsigned );
 	const int	slot_bytes = ( tile_bytes + 15 ) & ~15;
 	__shared__ long long	s_tile;
-	__shared__ int	s_seq, s_qn, s_qhead;
+	__shared__ int	s_seq, s_qn, s_qhead, s_dqn, s_dqhead;
 	__shared__ int	s_ctx[ G ][ G > 1 ? 8 : 1 ];	// G > 1: seq, comp, slen, z0, p_lo, vec_words of every slot
 	const int	tid = threadIdx.x;
 	// lanes that share a tile in pass A: the workgroup, or one wave per slot
@@ -351,7 +390,12 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
 	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
-	LdsGRecs<BLOCK>	gr{ lean_lo + threadIdx.x };		// (the general instance's records take the same place)
+	// (the general instance's records take the same place; behind them the resume states of the
+	// levels up to the split level and the queue of continuations)
+	const int	split_s = LEAN || ( dbg & 256 ) ? -1 : P->split_s;
+	uint32_t	*const g_before = lean_lo + 3 * P->n_searches * BLOCK;
+	uint32_t	*const g_deep = g_before + 2 * ( split_s + 1 ) * BLOCK;
+	LdsGRecs<BLOCK>	gr{ lean_lo + threadIdx.x, g_before + threadIdx.x };
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
 	const int	lit_n = lit ? rmd_regexes( P )[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
@@ -404,6 +448,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			s_seq = s;
 			s_qn = 0;
 			s_qhead = 0;
+			s_dqn = 0;
+			s_dqhead = 0;
 		}
 		__syncthreads();
 		const long long	t = s_tile;
@@ -780,30 +826,84 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		}else{
 			// every element type: 12 bytes of search state per level, in LDS (rmd_grec_t)
 			rmd_gen_t	st;
+			unsigned	cur_item = 0;
 			const RowEnds	ends{ pb, tile, pb_words, p_lo, ( dbg & 64 ) ? 0 : vec_words * 64 };	// (bit 64: end by end, no rows)
-			for( ; ; ){
-				const unsigned long long	want = __ballot( k < 0 && !dry );
-				if( want ){
-					int	base = 0;
-					if( lane_id == __ffsll( want ) - 1 )
-						base = atomicAdd( &s_qhead, __popcll( want ) );
-					base = __shfl( base, __ffsll( want ) - 1 );
-					if( k < 0 && !dry ){
-						const int	i = base + __popcll( want & lt_mask );
-						if( i < nq ){
-							const unsigned	item = i < qcap ? queue[ i ] :
-								__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-							const int	r = int( item & 0xffffu );
-							k = rmd_gen_begin( P, gr, st, z0 + int( item >> 16 ), slen,
-								r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
-						}else
-							dry = true;
+			const LdsSplit	split{ split_s, g_deep, &s_dqn, &cur_item };
+			// Two rounds over the tile.  Round 0: the work items, down to the split level; what
+			// survives there is queued as a continuation (LdsSplit), so the lanes stay together on the
+			// first levels.  Round 1: the continuations, each walked from below the split level to
+			// its end by one lane.  Without a split level round 0 walks everything.
+			for( int round = 0; round < ( split_s >= 0 ? 2 : 1 ); round++ ){
+				if( round == 1 ){
+					__syncthreads();
+					k = -1;
+					dry = false;
+				}
+				const int	n_work = round == 0 ? nq : ( s_dqn < DEEP_QUEUE ? s_dqn : DEEP_QUEUE );
+				int	*const head = round == 0 ? &s_qhead : &s_dqhead;
+				for( ; ; ){
+					const unsigned long long	want = __ballot( k < 0 && !dry );
+					if( want ){
+						int	base = 0;
+						if( lane_id == __ffsll( want ) - 1 )
+							base = atomicAdd( head, __popcll( want ) );
+						base = __shfl( base, __ffsll( want ) - 1 );
+						if( k < 0 && !dry ){
+							const int	i = base + __popcll( want & lt_mask );
+							if( i >= n_work )
+								dry = true;
+							else if( round == 0 ){
+								cur_item = i < qcap ? queue[ i ] :
+									__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+								const int	r = int( cur_item & 0xffffu );
+								k = rmd_gen_begin( P, gr, st, z0 + int( cur_item >> 16 ), slen,
+									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+							}else{
+								const uint32_t	*e = g_deep + i * split.entry_words();
+								cur_item = e[ 0 ];
+								const int	r = int( cur_item & 0xffffu );
+								k = rmd_gen_resume( P, gr, st, sq, z0 + int( cur_item >> 16 ), slen,
+									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1, split_s, e + 2, int( e[ 1 ] ), ends );
+							}
+						}
+					}
+					if( __ballot( k >= 0 ) == 0 )
+						break;
+					if( dbg & 32 ){
+						// diagnostic: per search level, wave rounds with a lane on it and lanes served
+						for( int kk = 0; kk < P->n_searches; kk++ ){
+							const unsigned long long	mk = __ballot( k == kk );
+							if( mk && lane_id == 0 ){
+								atomicAdd( hb.ticket + 15 + 2 * kk, 1ull );
+								atomicAdd( hb.ticket + 16 + 2 * kk, ( unsigned long long )__popcll( mk ) );
+							}
+						}
+					}
+					// Lanes on different levels run different code, one level after the other: serve the
+					// level most lanes are on and let the others wait for company (they are served once the
+					// lanes ahead of them have gone dry or caught up), instead of a round per level for a
+					// lane or two each.
+					int	serve = k;
+					if( !( dbg & 128 ) ){
+						int	most = 0;
+						for( int kk = 0; kk < P->n_searches; kk++ ){
+							const int	n = __popcll( __ballot( k == kk ) );
+							if( n > most ){
+								most = n;
+								serve = kk;
+							}
+						}
+					}
+					if( k >= 0 && k == serve ){
+						if( round == 0 )
+							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends, split );
+						else{
+							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends );
+							if( k <= split_s )
+								k = -1;		// back at the split level: this alternative is done
+						}
 					}
 				}
-				if( __ballot( k >= 0 ) == 0 )
-					break;
-				if( k >= 0 )
-					k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends );
 			}
 		}
 		PHASE( 4 );
@@ -949,6 +1049,8 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	lds += size_t( dp.n_searches ) * 256 * ( lean ? LEAN_REC_BYTES : GEN_REC_BYTES );
+	if( !lean && dp.split_s >= 0 )		// resume states of the levels up to the split level, queue of continuations
+		lds += size_t( dp.split_s + 1 ) * 256 * 8 + size_t( DEEP_QUEUE ) * ( 2 + 2 * ( dp.split_s + 1 ) ) * 4;
 	return lds;
 }
 
@@ -992,7 +1094,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		HIPCHK( hipMalloc( &sc->d_prog, size_t( sc->prog_bytes ) ) );
 		HIPCHK( hipMemcpy( sc->d_prog, img.data(), size_t( sc->prog_bytes ), hipMemcpyHostToDevice ) );
 	}
-	HIPCHK( hipMalloc( &sc->d_counters, 16 * sizeof( unsigned long long ) ) );
+	HIPCHK( hipMalloc( &sc->d_counters, 96 * sizeof( unsigned long long ) ) );
 	if( efn != nullptr ){
 		std::vector<int16_t>	t16;
 		std::vector<int32_t>	tlkey;
@@ -1345,7 +1447,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	int	grid = int( std::min<int64_t>( n_units, sc->grid_blocks ) );
 	unsigned long long	count = 0;
 	for( int attempt = 0; attempt < 2; attempt++ ){
-		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 16 * sizeof( unsigned long long ), sc->stream ) );
+		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 96 * sizeof( unsigned long long ), sc->stream ) );
 		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		if( grouped )
@@ -1372,6 +1474,11 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 				double	tot = 0;
 				for( int i = 0; i < 6; i++ )
 					tot += double( ph[ i ] );
+				unsigned long long	lv[ 64 ];
+				( void )hipMemcpy( lv, sc->d_counters + 16, sizeof( lv ), hipMemcpyDeviceToHost );
+				for( int kk = 0; kk < dp.n_searches && kk < 32 && !lean; kk++ )
+					fprintf( stderr, "[dbg] level %2d (element %2d, type %d): %llu wave rounds, %.1f lanes each\n", kk, dp.searches[ kk ],
+						dp.elems[ dp.searches[ kk ] ].type, lv[ 2 * kk ], lv[ 2 * kk ] ? double( lv[ 2 * kk + 1 ] ) / lv[ 2 * kk ] : 0.0 );
 				fprintf( stderr, "[dbg] wave cycles: decode %.1f%%, literal %.1f%%, rows %.1f%%, pre-filter %.1f%%, search %.1f%%, waiting %.1f%%\n",
 					100 * ph[ 0 ] / tot, 100 * ph[ 1 ] / tot, 100 * ph[ 2 ] / tot, 100 * ph[ 3 ] / tot, 100 * ph[ 4 ] / tot, 100 * ph[ 5 ] / tot );
 			}
@@ -1453,11 +1560,24 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 		keys[ i ].i = i;
 	}
 	lap( "keys" );
-	std::sort( keys.begin(), keys.end(), []( const Key &x, const Key &y ){ return x.a != y.a ? x.a < y.a : x.b < y.b; } );
+	// (a lane emits the candidates of one alternative in the reference's order and its slots in
+	// the hit buffer ascend: equal keys -- candidates of one continuation -- stay in buffer order)
+	std::sort( keys.begin(), keys.end(), []( const Key &x, const Key &y ){
+		return x.a != y.a ? x.a < y.a : x.b != y.b ? x.b < y.b : x.i < y.i; } );
 	lap( "sort" );
 	sc->h_sorted.resize( words );
-	for( int64_t i = 0; i < n; i++ )
-		memcpy( &sc->h_sorted[ size_t( i ) * stride ], d + keys[ i ].i * stride, stride * sizeof( int32_t ) );
+	// the order word becomes what the reference's walk would count: 0, 1, ... within (entry, strand, start, rank)
+	uint64_t	pa = ~0ull;
+	uint32_t	prank = 0, order = 0;
+	for( int64_t i = 0; i < n; i++ ){
+		int32_t	*o = &sc->h_sorted[ size_t( i ) * stride ];
+		memcpy( o, d + keys[ i ].i * stride, stride * sizeof( int32_t ) );
+		const uint32_t	rank = uint32_t( keys[ i ].b >> 32 );
+		order = ( keys[ i ].a == pa && rank == prank ) ? order + 1 : 0;
+		pa = keys[ i ].a;
+		prank = rank;
+		o[ 4 ] = int32_t( order );
+	}
 	lap( "ordering" );
 	*hits = sc->h_sorted.data();
 	return 0;

@@ -53,13 +53,36 @@ struct ArrRecs {
 // the general path's records, one per search level (the kernel keeps them packed in LDS)
 struct GenRecs {
 	rmd_grec_t	r[ RMD_MAX_ELEMS ];
+	uint32_t	before[ 2 * RMD_MAX_ELEMS ];
 	rmd_grec_t	get( int k ) const { return r[ k ]; }
 	void	set( int k, rmd_grec_t v ) { r[ k ] = v; }
 	void	set_iter( int k, rmd_grec_t v ) { r[ k ].sd = v.sd; r[ k ].a = v.a; r[ k ].c = v.c; r[ k ].hl = v.hl; r[ k ].ph = v.ph; }
+	void	set_iter_words( int k, uint32_t d1, uint32_t d2 ) { rmd_grec_set_words( r[ k ], d1, d2 ); }
+	void	set_before( int k, rmd_grec_t v ) { before[ 2 * k ] = rmd_grec_word1( v ); before[ 2 * k + 1 ] = rmd_grec_word2( v ); }
 	void	set_window( int k, int zero, int osd ) { r[ k ].zero = int16_t( zero ); r[ k ].osd = int16_t( osd ); }
 	void	set_zero( int k, int zero ) { r[ k ].zero = int16_t( zero ); }
 	void	set_osd( int k, int osd ) { r[ k ].osd = int16_t( osd ); }
 	int	hl( int k ) const { return r[ k ].hl; }
+};
+
+// continuations of the split level, as the kernel queues them (every third one is refused, as a
+// full queue would: the lane then walks the alternative itself)
+struct HostCont { int alt; uint32_t before[ 2 * RMD_MAX_ELEMS ]; };
+struct HostSplit {
+	int	S;
+	std::vector<HostCont>	*q;
+	int	*n_offered;
+	int	level() const { return S; }
+	bool	push( const rmd_gen_t &, GenRecs &gr, int alt ) const
+	{
+		if( ++*n_offered % 3 == 0 )
+			return false;
+		HostCont	c;
+		c.alt = alt;
+		memcpy( c.before, gr.before, sizeof( c.before ) );
+		q->push_back( c );
+		return true;
+	}
 };
 
 // rmd_gen_skip_ends()'s accelerator as the kernel defines it (RowEnds, rm_scan_hip.hip), bit by
@@ -110,7 +133,42 @@ static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t
 		GenRecs	recs;
 		memset( &recs, 0x55, sizeof( recs ) );	// (windows are written before they are read: any garbage must do)
 		HostEnds	ends{ dp, sq, slen };
-		rmd_gen_position( dp, recs, lane, sq, szero, slen, r0, cnt, sink, ends );
+		if( dp->split_s < 0 || getenv( "HOSTSIM_NOSPLIT" ) ){
+			rmd_gen_position( dp, recs, lane, sq, szero, slen, r0, cnt, sink, ends );
+			return;
+		}
+		// as the kernel does it: the first levels now, what they hand over afterwards; then the
+		// candidates of the item in the order the host restores (rank, alternative, emission)
+		std::vector<int32_t>	mine;
+		VecSink	tmp{ &mine, sink.seq, sink.comp, sink.stride };
+		std::vector<HostCont>	conts;
+		int	n_offered = 0;
+		HostSplit	split{ dp->split_s, &conts, &n_offered };
+		rmd_gen_t	st;
+		int	k = rmd_gen_begin( dp, recs, st, szero, slen, r0, cnt );
+		while( k >= 0 )
+			k = rmd_gen_step( dp, recs, st, sq, k, lane, tmp, ends, split );
+		for( const HostCont &c : conts ){
+			memset( &recs, 0x55, sizeof( recs ) );
+			k = rmd_gen_resume( dp, recs, st, sq, szero, slen, r0, cnt, dp->split_s, c.before, c.alt, ends );
+			while( k > dp->split_s )
+				k = rmd_gen_step( dp, recs, st, sq, k, lane, tmp, ends );
+		}
+		const int	stride = sink.stride;
+		std::vector<int>	idx( mine.size() / stride );
+		for( size_t i = 0; i < idx.size(); i++ )
+			idx[ i ] = int( i );
+		std::stable_sort( idx.begin(), idx.end(), [&]( int x, int y ){
+			const int32_t	*a = &mine[ size_t( x ) * stride ], *b = &mine[ size_t( y ) * stride ];
+			return a[ 3 ] != b[ 3 ] ? a[ 3 ] < b[ 3 ] : a[ 4 ] < b[ 4 ]; } );
+		int	prev_rank = -1, order = 0;
+		for( int i : idx ){
+			int32_t	*w = &mine[ size_t( i ) * stride ];
+			order = w[ 3 ] == prev_rank ? order + 1 : 0;
+			prev_rank = w[ 3 ];
+			w[ 4 ] = order;
+			sink.out->insert( sink.out->end(), w, w + stride );
+		}
 	}
 }
 
