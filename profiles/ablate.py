@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--record-len", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--env", action="append", default=[], help="NAME=VALUE set before the scanner is made")
+    ap.add_argument("--dbg-or", type=int, default=0, help="RNAMOTIF_DBG bits set in every measurement (64 no rows, 128 no level voting, 256 no split)")
+    ap.add_argument("--quick", action="store_true", help="whole kernel only")
     ap.add_argument("descr", nargs="+")
     args = ap.parse_args()
     for kv in args.env:
@@ -40,10 +42,9 @@ def main():
         db = sc.database(seqs)
         out = {"descr": os.path.basename(path), "bases": db.bases, "env": args.env}
         for name, dbg in (("all", None), ("pass_a_only", "1")):
-            if dbg is None:
-                os.environ.pop("RNAMOTIF_DBG", None)
-            else:
-                os.environ["RNAMOTIF_DBG"] = dbg
+            if dbg is not None and args.quick:
+                continue
+            os.environ["RNAMOTIF_DBG"] = str(int(dbg or 0) | args.dbg_or)
             sc.scan_device(db)
             ms = []
             for _ in range(args.reps):
@@ -53,10 +54,12 @@ def main():
             if dbg is None:
                 out["candidates"] = n
                 out["efn_ms"] = round(e_ms, 3)
-        os.environ["RNAMOTIF_DBG"] = "34"     # 2: count queued items, 32: wave cycles per phase
-        sys.stderr.flush()
-        sc.scan_device(db)      # prints "[dbg] queued items" on stderr
+        if not args.quick:
+            os.environ["RNAMOTIF_DBG"] = str(34 | args.dbg_or)     # 2: count queued items, 32: wave cycles per phase
+            sys.stderr.flush()
+            sc.scan_device(db)      # prints "[dbg] queued items" on stderr
         os.environ.pop("RNAMOTIF_DBG", None)
+        out["dbg_or"] = args.dbg_or
         out["gbases_per_s"] = round(db.bases / out["all_ms"] / 1e6, 2)
         print(json.dumps(out), flush=True)
         db.close()

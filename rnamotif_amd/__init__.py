@@ -21,7 +21,7 @@ from typing import Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librnamotif_amd.so")
+LIB_PATH = os.environ.get("RNAMOTIF_AMD_LIB") or os.path.join(_HERE, "librnamotif_amd.so")    # (the variable: build variants, profiles/variants.sh)
 EFNDATA_DIR = os.path.join(_HERE, "efndata")
 CLI_PATH = os.path.join(_HERE, "bin", "rnamotif")
 

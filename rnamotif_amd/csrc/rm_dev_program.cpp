@@ -72,6 +72,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		FAIL( "too many seq= expressions for the device scanner" );
 	out->n_elems = p->n_elems;
 	out->n_searches = p->n_searches;
+	out->step_budget = 32;
 	out->dminlen = p->dminlen;
 	out->w_winsize = p->dmaxlen < p->windowsize ? p->dmaxlen : p->windowsize;
 	out->strict_helices = p->strict_helices;

@@ -134,6 +134,7 @@ struct rmd_program_t {
 	int32_t	split_s;		// general path: alternatives of this level are handed over as continuations
 					// (rm_scan_core.h, rmd_gen_resume): the last of the helices that head the
 					// search list when levels follow it; -1: none
+	int32_t	step_budget;		// general path: loop iterations a step may take before it pauses (>= 4)
 	int32_t	need_init;		// some helix is improper: element state must start UNDEF
 	int32_t	lean_ok;		// every level is ss or a proper helix: 8-byte-per-level search
 	int32_t	has_lctx, has_rctx;

@@ -29,6 +29,10 @@
 #ifndef RMD_FN_MEMBER
 #define RMD_FN_MEMBER	inline
 #endif
+// the level generators of the general path (big, each with its own working set)
+#ifndef RMD_GEN_FN
+#define RMD_GEN_FN	RMD_COLD
+#endif
 #define RMD_UNDEF	(-1)
 
 // host-only instrumentation for tests/hostsim (never defined in the kernel build)
@@ -892,7 +896,16 @@ struct rmd_gen_t {
 	int32_t	pretested;	// the item is one end position that already passed the first-pairs test
 	int32_t	wend;		// last position of the item's window (relative)
 	int32_t	tag;		// >= 0: what candidates carry as their order (an alternative of the split level, below)
+	// A step does a bounded amount of work: the loops of the generators count their iterations down
+	// from budget0 and, at a point where the level's record says where they are, stop with
+	// paused set; the next step of the level goes on from there.  Lanes of a wave that share a
+	// level then leave a step together, whatever their items hold, and the ones that are done
+	// take new items -- instead of all waiting for the longest scan among them.
+	int32_t	budget, budget0, paused;
 };
+// (rmd_program_t::step_budget, at least 4: a step must get past the ticks of the nested loop heads --
+// generator, end position, scan of 3' ends -- to the one that comes after some progress)
+#define RMD_TICK( st_ )	( --( st_ ).budget < 0 ? ( ( st_ ).paused = 1 ) : 0 )
 
 // find_minlen()/find_maxlen() over range q of improper helix pk, find_motif.c:642-665
 template< class GR >
@@ -930,6 +943,8 @@ RMD_FN int rmd_gen_begin( const rmd_program_t *P, GR &gr, rmd_gen_t &st, int sze
 	st.rank = -1;
 	st.order = 0;
 	st.tag = -1;
+	st.budget0 = st.budget = P->step_budget;
+	st.paused = 0;
 	rmd_grec_t	r;
 	r.zero = 0;
 	r.osd = int16_t( rmd_imin( szero + P->w_winsize - 1, slen - 1 ) - szero );
@@ -982,7 +997,12 @@ RMD_FN bool rmd_pin_ok( const rmd_program_t *P, const rmd_seq_t &sq, int z, int 
 // mask for every end position top-63+i >= lo (absolute positions) at which the first minlen
 // pairs of helix stp with its 5' end at s5 stay within the mispair limit -- a superset of the
 // ends where match_wchlx() finds a candidate -- and returns false when it cannot tell.
+// The accelerator type also says which kinds of element the instance is compiled for (a kernel
+// instance per class of descriptor keeps the code, and with it the registers, of the others out):
+#define RMD_KIND_PK	1	// improper (pseudoknot) helices
+#define RMD_KIND_TQ	2	// parallel helices, triplexes, 4-plexes
 struct rmd_no_ends_t {
+	static constexpr int	kinds = RMD_KIND_PK | RMD_KIND_TQ;
 	RMD_FN_MEMBER bool	ends( const rmd_elem_t &, int, int, int, uint64_t * ) const { return false; }
 };
 
@@ -990,10 +1010,12 @@ struct rmd_no_ends_t {
 // Returns with *top at the next end worth a full match, or below lo.
 template< class Accel >
 RMD_FN void rmd_gen_skip_ends( const rmd_program_t *P, const rmd_seq_t &sq, const rmd_elem_t &stp, const Accel &accel,
-	int z, int s5, int i_minl, int lo, int *top )
+	int z, int s5, int i_minl, int lo, int *top, rmd_gen_t &st )
 {
 	int	e = *top;
 	while( e >= lo ){
+		if( RMD_TICK( st ) )
+			break;		// (paused: *top says how far the scan got)
 		uint64_t	m;
 		if( accel.ends( stp, z + s5, z + e, z + lo, &m ) ){
 			if( m != 0 ){
@@ -1024,10 +1046,14 @@ RMD_FN bool rmd_gen_next_sd( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 			// end positions whose first base pairs cannot start this helix are skipped at once: they
 			// have no effect that outlives the iteration (find_motif.c:273-280, 1010-1021)
 			int	e = r.sd;
-			rmd_gen_skip_ends( P, sq, stp, accel, z, r.zero, stp.q_iminl, lo, &e );
+			rmd_gen_skip_ends( P, sq, stp, accel, z, r.zero, stp.q_iminl, lo, &e, st );
 			r.sd = int16_t( e < lo ? lo - 1 : e );
+			if( st.paused )
+				return false;
 		}
 		if( r.sd < lo )
+			return false;
+		if( RMD_TICK( st ) )
 			return false;
 		*cur = r.sd--;
 		// an end position after which the next group's anchored seq= cannot start leads nowhere
@@ -1048,7 +1074,7 @@ RMD_FN bool rmd_gen_next_sd( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 // Advance level k to its next alternative: true with the alternative recorded in r and the
 // windows of the levels it opens set, false when the level is exhausted.
 template< class GR, class Accel >
-RMD_FN bool rmd_gen_ss( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+RMD_GEN_FN bool rmd_gen_ss( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_ss :332
 {
 	r.ph = 0;
@@ -1068,7 +1094,7 @@ RMD_FN bool rmd_gen_ss( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd
 }
 
 template< class GR, class Accel >
-RMD_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+RMD_GEN_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_wchlx :400
 {
 	const int	z = st.szero, d = P->searches[ k ];
@@ -1111,7 +1137,7 @@ RMD_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const 
 // helix' 3' strand (the hlx == 2 test, :613-627).  The reference tests that per matched length;
 // here the same inequalities bound the 5' starts, 3' ends and lengths that are tried at all.
 template< class GR, class Accel >
-RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+RMD_GEN_FN bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )
 {
 	const int	z = st.szero, d = P->searches[ k ], d3 = stp.mates[ 0 ];
@@ -1185,6 +1211,8 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 		}
 	}
 	for( ; ; ){
+		if( r.ph != 3 && RMD_TICK( st ) )
+			return false;		// (phases 0..2 are all in the record)
 		if( r.ph == 0 ){
 			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ) )
 				return false;
@@ -1221,8 +1249,10 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 			// 3' ends whose first pairs cannot start the helix change nothing: skip them
 			{
 				int	e = r.c;
-				rmd_gen_skip_ends( P, sq, stp, accel, z, s5, i_minl, l_s3, &e );
+				rmd_gen_skip_ends( P, sq, stp, accel, z, s5, i_minl, l_s3, &e, st );
 				r.c = int16_t( e < l_s3 ? l_s3 - 1 : e );
+				if( st.paused )
+					return false;
 			}
 			if( r.c < l_s3 ){
 				r.ph = 1;
@@ -1280,7 +1310,7 @@ RMD_COLD bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 }
 
 template< class GR, class Accel >
-RMD_COLD bool rmd_gen_phlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+RMD_GEN_FN bool rmd_gen_phlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_phlx :703
 {
 	const int	z = st.szero, d = P->searches[ k ];
@@ -1303,7 +1333,7 @@ RMD_COLD bool rmd_gen_phlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 }
 
 template< class GR, class Accel >
-RMD_COLD bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+RMD_GEN_FN bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_triplex :763
 {
 	const int	z = st.szero, d = P->searches[ k ], d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
@@ -1331,6 +1361,8 @@ RMD_COLD bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 		if( ( stp.ends & RMA_5PAIRED ) && stp.tup >= 0 )
 			m2 = rmd_tups( P )[ stp.tup ].t2[ rmd_code( sq, z + r.zero ) * 5 + rmd_code( sq, z + cur - hlen + 1 ) ];
 		while( r.a >= last ){
+			if( RMD_TICK( st ) )
+				return false;
 			const int	s = r.a--;
 			if( !( ( m2 >> rmd_code( sq, z + s ) ) & 1 ) )
 				continue;
@@ -1354,7 +1386,7 @@ RMD_COLD bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 
 // Phases: 1 next length of the outer helix, 2 next (s1, s2) of the inner strands.
 template< class GR, class Accel >
-RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
+RMD_GEN_FN bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_4plex :851, find_4plex_inner :902
 {
 	const int	z = st.szero, d = P->searches[ k ];
@@ -1405,6 +1437,8 @@ RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 		const int	b14 = rmd_code( sq, z + r.zero + hl - 1 ) * 5 + rmd_code( sq, z + cur - hl + 1 );
 		const unsigned	m2 = prune ? tup.q2[ b14 ] : 0x1fu;
 		while( r.a <= s1lim ){
+			if( RMD_TICK( st ) )
+				return false;
 			const int	s1 = r.a;
 			const int	b2 = rmd_code( sq, z + s1 );
 			if( r.c < s1 + 2 * hl + stp1.minilen || !( ( m2 >> b2 ) & 1 ) ){
@@ -1440,9 +1474,10 @@ RMD_COLD bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, cons
 
 // Rebuild the element table of the current path into L (every level holds an alternative)
 // and run the end-of-list checks (find_ss :362-393).
-template< class GR, class Sink >
-RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, rmd_lane_t *L, Sink &sink )
+template< int KINDS, class GR, class Sink >
+RMD_GEN_FN void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, rmd_lane_t *L, Sink &sink )
 {
+	constexpr bool	PK = ( KINDS & RMD_KIND_PK ) != 0, TQ = ( KINDS & RMD_KIND_TQ ) != 0;
 	const int	z = st.szero;
 	for( int k = 0; k < P->n_searches; k++ ){
 		const rmd_grec_t	r = gr.get( k );
@@ -1464,6 +1499,7 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 			const int	d3 = stp.mates[ 0 ], hl = r.hl;
 			uint64_t	cand, mis;
 			int	s5 = zero, s3 = cur, i_minl = stp.minilen, mm5 = 0, mm3 = 0;
+			if constexpr( PK ){
 			if( !stp.proper ){
 				// s_n_mismatches of a knot's strands is not reset per attempt (find_pknot3): what
 				// the search started with unless this match's chk_seq() calls count them
@@ -1472,6 +1508,7 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 				s3 = z + r.c + 1;
 				rmd_pk_len( rmd_pks( P )[ stp.pk ], gr, RMD_PK_I, &i_minl, &i_maxl );
 				mm5 = mm3 = RMD_UNDEF;
+			}
 			}
 			rmd_match_wchlx_mm( P, sq, d, d3, s5, s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
 			const int	mpr = rmd_popc64( mis & ( ( 1ull << hl ) - 1 ) );
@@ -1484,7 +1521,7 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 			L->mm[ d3 ] = int16_t( mm3 );
 			break;
 		}
-		case RMA_T_P5 : {
+		case RMA_T_P5 : if constexpr( TQ ){
 			const int	d3 = stp.mates[ 0 ];
 			int	s5hi, s5lo, hlen = 0, n_mpr = 0, mm5 = 0, mm3 = 0;
 			rmd_phlx_bounds( zero, cur - zero + 1, stp.minlen, stp.maxlen, stp.minilen, stp.maxilen, &s5hi, &s5lo );
@@ -1498,7 +1535,7 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 			L->mm[ d3 ] = int16_t( mm3 );
 			break;
 		}
-		case RMA_T_T1 : {
+		case RMA_T_T1 : if constexpr( TQ ){
 			const int	d1 = stp.scopes[ 1 ], d2 = stp.scopes[ 2 ];
 			const rmd_elem_t	&stp1 = P->elems[ d1 ];
 			int	s5hi, s5lo, hlen = 0, n_mpr = 0, mm5 = 0, mm3 = 0, mm1 = 0;
@@ -1517,7 +1554,7 @@ RMD_COLD void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const
 			L->mm[ d2 ] = int16_t( mm3 );
 			break;
 		}
-		case RMA_T_Q1 : {
+		case RMA_T_Q1 : if constexpr( TQ ){
 			const int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ], hl = r.hl;
 			const int	i_minl = stp.minilen + P->elems[ d1 ].minilen + P->elems[ d2 ].minilen + 2 * stp.minlen;
 			uint64_t	cand, mis;
@@ -1563,17 +1600,28 @@ template< class GR, class Accel >
 RMD_FN bool rmd_gen_next( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k,
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )
 {
+	constexpr bool	PK = ( Accel::kinds & RMD_KIND_PK ) != 0, TQ = ( Accel::kinds & RMD_KIND_TQ ) != 0;
 	switch( stp.type ){
 	case RMA_T_SS :
 		return rmd_gen_ss( P, gr, st, sq, k, stp, r, accel );
 	case RMA_T_H5 :
-		return stp.proper ? rmd_gen_wchlx( P, gr, st, sq, k, stp, r, accel ) : rmd_gen_pknot( P, gr, st, sq, k, stp, r, accel );
+		if constexpr( PK ){
+			if( !stp.proper )
+				return rmd_gen_pknot( P, gr, st, sq, k, stp, r, accel );
+		}
+		return rmd_gen_wchlx( P, gr, st, sq, k, stp, r, accel );
 	case RMA_T_P5 :
-		return rmd_gen_phlx( P, gr, st, sq, k, stp, r, accel );
+		if constexpr( TQ )
+			return rmd_gen_phlx( P, gr, st, sq, k, stp, r, accel );
+		return false;
 	case RMA_T_T1 :
-		return rmd_gen_triplex( P, gr, st, sq, k, stp, r, accel );
+		if constexpr( TQ )
+			return rmd_gen_triplex( P, gr, st, sq, k, stp, r, accel );
+		return false;
 	case RMA_T_Q1 :
-		return rmd_gen_4plex( P, gr, st, sq, k, stp, r, accel );
+		if constexpr( TQ )
+			return rmd_gen_4plex( P, gr, st, sq, k, stp, r, accel );
+		return false;
 	default :
 		return false;
 	}
@@ -1630,11 +1678,17 @@ RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rm
 	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
 	const int	S = split.level();
 	rmd_grec_t	r = gr.get( k );
+	st.budget = st.budget0;
+	st.paused = 0;
 	for( ; ; ){
 		if( S >= 0 && k <= S )
 			gr.set_before( k, r );		// what this alternative's generator is resumed from
-		if( !rmd_gen_next( P, gr, st, sq, k, stp, r, accel ) )
-			return stp.back_s;
+		if( !rmd_gen_next( P, gr, st, sq, k, stp, r, accel ) ){
+			if( !st.paused )
+				return stp.back_s;
+			gr.set_iter( k, r );		// out of budget: the level goes on from here at its next step
+			return k;
+		}
 		gr.set_iter( k, r );
 		const int	j = rmd_gen_descend( P, gr, st, sq, k );
 		if( j < 0 )
@@ -1650,7 +1704,7 @@ RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rm
 			rmd_gen_open( P, gr, j );
 			return j;
 		}
-		rmd_gen_emit( P, gr, st, sq, L, sink );
+		rmd_gen_emit<Accel::kinds>( P, gr, st, sq, L, sink );
 		return k;
 	}
 }
@@ -1664,6 +1718,7 @@ RMD_FN int rmd_gen_resume( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const 
 	int szero, int slen, int r0, int cnt, int S, const uint32_t *before, int alt, const Accel &accel )
 {
 	rmd_gen_begin( P, gr, st, szero, slen, r0, cnt );
+	st.budget = 0x7fffffff;		// (reproducing an alternative is not a step to be cut short)
 	for( int j = 0; j <= S; j++ ){
 		gr.set_iter_words( j, before[ 2 * j ], before[ 2 * j + 1 ] );
 		rmd_grec_t	r = gr.get( j );
@@ -1674,7 +1729,7 @@ RMD_FN int rmd_gen_resume( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const 
 			const int	cur = r.sd + 1;
 			if( stp.loop && stp.next_s >= 0 )
 				gr.set_window( stp.next_s, cur + 1, r.osd );
-			if( stp.type == RMA_T_H5 && !stp.proper && stp.scope == 0 ){
+			if( ( Accel::kinds & RMD_KIND_PK ) && stp.type == RMA_T_H5 && !stp.proper && stp.scope == 0 ){
 				const rmd_pk_t	&pk = rmd_pks( P )[ stp.pk ];
 				for( int x = 1; x < stp.n_scopes; x++ )
 					if( P->elems[ stp.scopes[ x ] ].type == RMA_T_H5 )

@@ -182,7 +182,7 @@ struct LdsGRecs {
 // rmd_gen_step()'s hand-over of the alternatives of the split level: a queue of continuations in
 // LDS, walked in the tile's second round.  Entry: the work item, the alternative's number, and
 // two words per level 0..S (LdsGRecs::set_before).  A full queue refuses: the lane walks on itself.
-#define DEEP_QUEUE	512
+#define DEEP_QUEUE	128
 struct LdsSplit {
 	int	S;
 	uint32_t	*dq;
@@ -298,7 +298,9 @@ __device__ inline unsigned long long rows_win( const unsigned long long *rows5, 
 
 // rmd_gen_skip_ends()'s accelerator: the 3' ends that can start helix stp, from the pair rows of
 // its pair table (rmd_elem_t::rows names the row set; -1: none, the core tests end by end)
+template< int KINDS >
 struct RowEnds {
+	static constexpr int	kinds = KINDS;	// element kinds the instance is compiled for (rm_scan_core.h)
 	const unsigned long long	*rows;		// row set 0; set j at rows + 5 * j * pb_words
 	const uint8_t	*tile;
 	int	pb_words, p_lo, vec_bits;
@@ -316,6 +318,127 @@ struct RowEnds {
 	}
 };
 
+// ---------------------------------------------------------------- general instance, pass B
+// What the search of a tile needs of the kernel's state: pass B of the general instance.  (The
+// pre-filter no longer searches queue overflow in place -- three inlined copies of the state
+// machine in its loops made them 2-3 times slower; the host repeats the launch with a larger
+// spill area instead, rma_scan_device.)
+struct GenTile {
+	const rmd_program_t	*P;
+	uint32_t	*recs, *before, *deep;		// LDS: records, resume states, queue of continuations
+	const unsigned	*queue, *spill;
+	int	qcap, nq;
+	int	*qhead, *dqn, *dqhead;			// LDS counters
+	const unsigned long long	*pb;
+	const uint8_t	*tile;
+	int	pb_words, p_lo, vec_words, slen, z0, split_s, dbg;
+};
+
+// (inlined: as a function of its own, called once per tile, it ran 15-25 % slower -- profiles/matrix_r2.sh)
+#ifndef PASS_B_ATTR
+#define PASS_B_ATTR	__attribute__(( always_inline ))
+#endif
+template< int BLOCK, int KINDS >
+__device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
+{
+	const rmd_program_t	*const P = gt.P;
+	const int	lane_id = threadIdx.x & 63, dbg = gt.dbg, qcap = gt.qcap, nq = gt.nq, split_s = gt.split_s;
+	const int	slen = gt.slen, z0 = gt.z0, p_lo = gt.p_lo, pb_words = gt.pb_words, vec_words = gt.vec_words;
+	const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
+	const unsigned	*const queue = gt.queue, *const spill = gt.spill;
+	const unsigned long long	*const pb = gt.pb;
+	const uint8_t	*const tile = gt.tile;
+	uint32_t	*const g_deep = gt.deep;
+	int	&s_qhead = *gt.qhead, &s_dqn = *gt.dqn, &s_dqhead = *gt.dqhead;
+	const HitBuf	&hb = sink.hb;
+	LdsGRecs<BLOCK>	gr{ gt.recs + threadIdx.x, gt.before + threadIdx.x };
+	rmd_seq_t	sq{ tile, p_lo };
+	rmd_lane_t	lane;
+	int	k = -1;
+	bool	dry = false;
+			// every element type: 12 bytes of search state per level, in LDS (rmd_grec_t)
+			rmd_gen_t	st;
+			unsigned	cur_item = 0;
+			const RowEnds<KINDS>	ends{ pb, tile, pb_words, p_lo, ( dbg & 64 ) ? 0 : vec_words * 64 };	// (bit 64: end by end, no rows)
+			const LdsSplit	split{ split_s, g_deep, &s_dqn, &cur_item };
+			// Two rounds over the tile.  Round 0: the work items, down to the split level; what
+			// survives there is queued as a continuation (LdsSplit), so the lanes stay together on the
+			// first levels.  Round 1: the continuations, each walked from below the split level to
+			// its end by one lane.  Without a split level round 0 walks everything.
+			for( int round = 0; round < ( split_s >= 0 ? 2 : 1 ); round++ ){
+				if( round == 1 ){
+					__syncthreads();
+					k = -1;
+					dry = false;
+				}
+				const int	n_work = round == 0 ? nq : ( s_dqn < DEEP_QUEUE ? s_dqn : DEEP_QUEUE );
+				int	*const head = round == 0 ? &s_qhead : &s_dqhead;
+				for( ; ; ){
+					const unsigned long long	want = __ballot( k < 0 && !dry );
+					if( want ){
+						int	base = 0;
+						if( lane_id == __ffsll( want ) - 1 )
+							base = atomicAdd( head, __popcll( want ) );
+						base = __shfl( base, __ffsll( want ) - 1 );
+						if( k < 0 && !dry ){
+							const int	i = base + __popcll( want & lt_mask );
+							if( i >= n_work )
+								dry = true;
+							else if( round == 0 ){
+								cur_item = i < qcap ? queue[ i ] :
+									__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+								const int	r = int( cur_item & 0xffffu );
+								k = rmd_gen_begin( P, gr, st, z0 + int( cur_item >> 16 ), slen,
+									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+							}else{
+								const uint32_t	*e = g_deep + i * split.entry_words();
+								cur_item = e[ 0 ];
+								const int	r = int( cur_item & 0xffffu );
+								k = rmd_gen_resume( P, gr, st, sq, z0 + int( cur_item >> 16 ), slen,
+									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1, split_s, e + 2, int( e[ 1 ] ), ends );
+							}
+						}
+					}
+					if( __ballot( k >= 0 ) == 0 )
+						break;
+					if( dbg & 32 ){
+						// diagnostic: per search level, wave rounds with a lane on it and lanes served
+						for( int kk = 0; kk < P->n_searches; kk++ ){
+							const unsigned long long	mk = __ballot( k == kk );
+							if( mk && lane_id == 0 ){
+								atomicAdd( hb.ticket + 15 + 2 * kk, 1ull );
+								atomicAdd( hb.ticket + 16 + 2 * kk, ( unsigned long long )__popcll( mk ) );
+							}
+						}
+					}
+					// Lanes on different levels run different code, one level after the other: serve the
+					// level most lanes are on and let the others wait for company (they are served once the
+					// lanes ahead of them have gone dry or caught up), instead of a round per level for a
+					// lane or two each.
+					int	serve = k;
+					if( !( dbg & 128 ) ){
+						int	most = 0;
+						for( int kk = 0; kk < P->n_searches; kk++ ){
+							const int	n = __popcll( __ballot( k == kk ) );
+							if( n > most ){
+								most = n;
+								serve = kk;
+							}
+						}
+					}
+					if( k >= 0 && k == serve ){
+						if( round == 0 )
+							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends, split );
+						else{
+							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends );
+							if( k <= split_s )
+								k = -1;		// back at the split level: this alternative is done
+						}
+					}
+				}
+			}
+		}
+
 // ---------------------------------------------------------------- search kernel
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
@@ -323,11 +446,15 @@ struct RowEnds {
 // LEAN: the descriptor has only ss and proper helices (rmd_program_t::lean_ok) -- pass B keeps
 // 8 bytes of state per level in LDS; the general state machine is not compiled into that
 // instance at all (no scratch frames, fewer registers).
-// (the general instance keeps its frames in scratch and is latency bound on them: six
-// waves per SIMD at 80 VGPRs beat four at 128 -- pk1 48.5 -> 41.9 ms, qu+tr 124 -> 94 ms)
+// (the general instance is bound by the latency of its dependent LDS accesses: four workgroups per
+// CU where its records, 12 bytes per level and lane, leave room for them -- measured against three
+// at 168 registers and against out-of-line level generators, profiles/matrix_r2.sh)
 #ifndef GENERAL_WAVES_PER_SIMD
 #define GENERAL_WAVES_PER_SIMD	4
 #endif
+// (... three with 168 registers for descriptors with triplexes / 4-plexes: qu+tr 46.4 -> 39.2 ms, where
+// pk1 goes 7.5 -> 8.6 ms)
+#define GENERAL_WAVES( kinds_ )	( ( ( kinds_ ) & RMD_KIND_TQ ) ? 3 : GENERAL_WAVES_PER_SIMD )
 #ifndef SHORT_GROUP
 #define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
 #endif
@@ -337,8 +464,10 @@ struct RowEnds {
 // entries, lean descriptors only): a group of G small tiles, each in its own LDS slot and
 // pre-filtered by one wave, feeding ONE work queue -- a tile of a 500 base entry yields a few
 // dozen items, far too few for 256 lanes, and pass B is where the time goes.
-template< int BLOCK, bool LEAN, int G >
-__global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES_PER_SIMD )
+// KINDS (general instance): the element kinds it is compiled for, RMD_KIND_PK | RMD_KIND_TQ -- an
+// instance per class of descriptor, so that a pseudoknot search does not carry the 4-plex code.
+template< int BLOCK, bool LEAN, int G, int KINDS = 0 >
+__global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES( KINDS ) )
 rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	static_assert( G == 1 || ( LEAN && G % ( BLOCK / 64 ) == 0 && G <= 32 ), "tile groups: lean path, whole rounds of waves" );
@@ -584,8 +713,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					int	k_ = rmd_lean_begin( P, lr, st_, szero_, slen, r0_, cnt_ ); \
 					while( k_ >= 0 ) \
 						k_ = rmd_lean_step( P, lr, st_, sq, k_, &lane, sink ); \
-				}else \
-					rmd_gen_position( P, gr, &lane, sq, szero_, slen, r0_, cnt_, sink ); \
+				} \
+				/* (general instance: the launch is repeated with a spill area that holds the tile's items) */ \
 			} \
 		} }while( 0 )
 
@@ -751,6 +880,12 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		// that finishes its item pops the next one at once (wave-aggregated pop), so a
 		// wave lasts as long as its share of the work, not as its slowest item times
 		// the number of rounds.
+		if constexpr( !LEAN ){
+			// more items than queue and spill area hold: none is searched twice or dropped silently --
+			// the host repeats the launch with an area of the size asked for here
+			if( tid == 0 && s_qn > qtotal )
+				atomicMax( hb.ticket + 2, ( unsigned long long )s_qn );
+		}
 		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < qtotal ? s_qn : qtotal );
 		if( ( dbg & 2 ) && tid == 0 )
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
@@ -824,87 +959,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink, accel );
 			}
 		}else{
-			// every element type: 12 bytes of search state per level, in LDS (rmd_grec_t)
-			rmd_gen_t	st;
-			unsigned	cur_item = 0;
-			const RowEnds	ends{ pb, tile, pb_words, p_lo, ( dbg & 64 ) ? 0 : vec_words * 64 };	// (bit 64: end by end, no rows)
-			const LdsSplit	split{ split_s, g_deep, &s_dqn, &cur_item };
-			// Two rounds over the tile.  Round 0: the work items, down to the split level; what
-			// survives there is queued as a continuation (LdsSplit), so the lanes stay together on the
-			// first levels.  Round 1: the continuations, each walked from below the split level to
-			// its end by one lane.  Without a split level round 0 walks everything.
-			for( int round = 0; round < ( split_s >= 0 ? 2 : 1 ); round++ ){
-				if( round == 1 ){
-					__syncthreads();
-					k = -1;
-					dry = false;
-				}
-				const int	n_work = round == 0 ? nq : ( s_dqn < DEEP_QUEUE ? s_dqn : DEEP_QUEUE );
-				int	*const head = round == 0 ? &s_qhead : &s_dqhead;
-				for( ; ; ){
-					const unsigned long long	want = __ballot( k < 0 && !dry );
-					if( want ){
-						int	base = 0;
-						if( lane_id == __ffsll( want ) - 1 )
-							base = atomicAdd( head, __popcll( want ) );
-						base = __shfl( base, __ffsll( want ) - 1 );
-						if( k < 0 && !dry ){
-							const int	i = base + __popcll( want & lt_mask );
-							if( i >= n_work )
-								dry = true;
-							else if( round == 0 ){
-								cur_item = i < qcap ? queue[ i ] :
-									__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-								const int	r = int( cur_item & 0xffffu );
-								k = rmd_gen_begin( P, gr, st, z0 + int( cur_item >> 16 ), slen,
-									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
-							}else{
-								const uint32_t	*e = g_deep + i * split.entry_words();
-								cur_item = e[ 0 ];
-								const int	r = int( cur_item & 0xffffu );
-								k = rmd_gen_resume( P, gr, st, sq, z0 + int( cur_item >> 16 ), slen,
-									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1, split_s, e + 2, int( e[ 1 ] ), ends );
-							}
-						}
-					}
-					if( __ballot( k >= 0 ) == 0 )
-						break;
-					if( dbg & 32 ){
-						// diagnostic: per search level, wave rounds with a lane on it and lanes served
-						for( int kk = 0; kk < P->n_searches; kk++ ){
-							const unsigned long long	mk = __ballot( k == kk );
-							if( mk && lane_id == 0 ){
-								atomicAdd( hb.ticket + 15 + 2 * kk, 1ull );
-								atomicAdd( hb.ticket + 16 + 2 * kk, ( unsigned long long )__popcll( mk ) );
-							}
-						}
-					}
-					// Lanes on different levels run different code, one level after the other: serve the
-					// level most lanes are on and let the others wait for company (they are served once the
-					// lanes ahead of them have gone dry or caught up), instead of a round per level for a
-					// lane or two each.
-					int	serve = k;
-					if( !( dbg & 128 ) ){
-						int	most = 0;
-						for( int kk = 0; kk < P->n_searches; kk++ ){
-							const int	n = __popcll( __ballot( k == kk ) );
-							if( n > most ){
-								most = n;
-								serve = kk;
-							}
-						}
-					}
-					if( k >= 0 && k == serve ){
-						if( round == 0 )
-							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends, split );
-						else{
-							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends );
-							if( k <= split_s )
-								k = -1;		// back at the split level: this alternative is done
-						}
-					}
-				}
-			}
+			GenTile	gt{ P, lean_lo, g_before, g_deep, queue, spill, qcap, nq, &s_qhead, &s_dqn, &s_dqhead,
+				pb, tile, pb_words, p_lo, vec_words, slen, z0, split_s, dbg };
+			general_pass_b<BLOCK, KINDS>( gt, sink );
 		}
 		PHASE( 4 );
 		__syncthreads();
@@ -1073,6 +1130,8 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		delete sc;
 		return 1;
 	}
+	if( const char *sb = getenv( "RNAMOTIF_BUDGET" ) )		// launch-shape switch: iterations per step
+		sc->dprog.step_budget = std::max( 4, atoi( sb ) );
 	for( int k = 0; k < prog->n_efn_sites; k++ ){
 		if( prog->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
 			sc->need_efn2 = true;	// tables come with rma_scanner_set_efn2data(), checked at the first scan
@@ -1174,13 +1233,20 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	}
 	if( !sc->dprog.lean_ok ){
 		// general instance: its records take 12 bytes per level and lane of LDS next to the tile;
-		// as many workgroups per CU as still leave a tile of a few thousand positions
-		sc->qcap = 1024;
+		// as many workgroups per CU as still leave a tile of a few thousand positions (what the
+		// queue cannot hold spills to HBM)
+		sc->qcap = 512;
 		sc->tile_t = 1024;
 		bool	found = false;
-		for( int wg = GENERAL_WAVES_PER_SIMD; wg >= 1 && !found; wg-- ){
-			const size_t	budget = ( 160 * 1024 ) / wg - 64;
-			for( int t = 8192; t >= ( wg > 1 ? 4096 : 1024 ); t -= 256 )
+		int	kinds = 0;
+		for( int k = 0; k < sc->dprog.n_searches; k++ ){
+			const int	t = sc->dprog.elems[ sc->dprog.searches[ k ] ].type;
+			if( t == RMA_T_P5 || t == RMA_T_T1 || t == RMA_T_Q1 )
+				kinds |= RMD_KIND_TQ;
+		}
+		for( int wg = GENERAL_WAVES( kinds ); wg >= 1 && !found; wg-- ){
+			const size_t	budget = ( 160 * 1024 ) / wg - 1024;	// (static __shared__ and allocation granules)
+			for( int t = 8192; t >= ( wg > 1 ? 3072 : 1024 ); t -= 256 )
 				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, false, sc->qcap ) <= budget ){
 					sc->tile_t = t;
 					found = true;
@@ -1439,26 +1505,30 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
 		return 1;
 	}
-	HIPCHK( hipFuncSetAttribute( grouped ? reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, true, SHORT_GROUP> ) :
-		lean ? reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, true, 1> ) :
-		reinterpret_cast<const void *>( &rma_search_kernel<BLOCK, false, 1> ),
-		hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	// the kernel instance: lean (one tile or a group of small ones per pass), or the general one
+	// compiled for the kinds of element the descriptor has
+	int	kinds = 0;
+	for( int k = 0; k < dp.n_searches; k++ ){
+		const rmd_elem_t	&e = dp.elems[ dp.searches[ k ] ];
+		if( e.type == RMA_T_H5 && !e.proper )
+			kinds |= RMD_KIND_PK;
+		if( e.type == RMA_T_P5 || e.type == RMA_T_T1 || e.type == RMA_T_Q1 )
+			kinds |= RMD_KIND_TQ;
+	}
+	typedef void	( *kernel_t )( const rmd_program_t *, int, int, DbView, HitBuf, int, int );
+	const kernel_t	kernel = grouped ? &rma_search_kernel<BLOCK, true, SHORT_GROUP> : lean ? &rma_search_kernel<BLOCK, true, 1> :
+		kinds == 0 ? &rma_search_kernel<BLOCK, false, 1, 0> : kinds == RMD_KIND_PK ? &rma_search_kernel<BLOCK, false, 1, RMD_KIND_PK> :
+		kinds == RMD_KIND_TQ ? &rma_search_kernel<BLOCK, false, 1, RMD_KIND_TQ> : &rma_search_kernel<BLOCK, false, 1, RMD_KIND_PK | RMD_KIND_TQ>;
+	HIPCHK( hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t	n_units = grouped ? ( db->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : db->n_tiles;
 	int	grid = int( std::min<int64_t>( n_units, sc->grid_blocks ) );
 	unsigned long long	count = 0;
-	for( int attempt = 0; attempt < 2; attempt++ ){
+	for( int attempt = 0; attempt < 4; attempt++ ){
 		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 96 * sizeof( unsigned long long ), sc->stream ) );
 		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
-		if( grouped )
-			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true, SHORT_GROUP> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
-		else if( lean )
-			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, true, 1> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
-		else
-			hipLaunchKernelGGL( ( rma_search_kernel<BLOCK, false, 1> ), dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-				sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
+		hipLaunchKernelGGL( kernel, dim3( grid ), dim3( BLOCK ), lds, sc->stream,
+			sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );
@@ -1483,9 +1553,25 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 					100 * ph[ 0 ] / tot, 100 * ph[ 1 ] / tot, 100 * ph[ 2 ] / tot, 100 * ph[ 3 ] / tot, 100 * ph[ 4 ] / tot, 100 * ph[ 5 ] / tot );
 			}
 		}
+		if( !lean ){
+			// the general instance does not search queue overflow in place: a larger spill area, and again
+			unsigned long long	need = 0;
+			HIPCHK( hipMemcpy( &need, sc->d_counters + 3, sizeof( need ), hipMemcpyDeviceToHost ) );
+			if( need > 0 ){
+				if( attempt == 3 ){
+					snprintf( err, errlen, "work queue overflow after regrow (%llu items in a tile)", need );
+					return 1;
+				}
+				( void )hipFree( sc->d_spill );
+				sc->d_spill = nullptr;
+				sc->spill_cap = int( need ) + 1024;
+				HIPCHK( hipMalloc( &sc->d_spill, size_t( sc->grid_blocks ) * sc->spill_cap * sizeof( unsigned ) ) );
+				continue;
+			}
+		}
 		if( int64_t( count ) <= sc->hit_cap )
 			break;
-		if( attempt == 1 ){
+		if( attempt == 3 ){
 			snprintf( err, errlen, "hit buffer overflow after regrow (%llu candidates)", count );
 			return 1;
 		}

@@ -46,6 +46,7 @@ def one(job):
         env = dict(os.environ)
         if kind == "lean-as-general":
             env["HOSTSIM_NOLEAN"] = "1"
+        env["HOSTSIM_BUDGET"] = str((4, 5, 7, 32)[seed % 4])    # steps that pause after that many iterations
         try:
             p = subprocess.run([BIN] + argv + [fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
         except subprocess.TimeoutExpired:

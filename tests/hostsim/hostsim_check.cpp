@@ -15,6 +15,9 @@
 #include "rm_oracle.h"
 #define RMD_FN static inline
 #define RMD_FN_MEMBER inline
+// (HOSTSIM_BUDGET: iterations a step of the general path may take before it pauses; small values make
+// every loop of the generators stop and resume)
+static int	hostsim_budget = 0;
 #include "rm_scan_core.h"
 #include "rm_efn2_core.h"
 
@@ -232,6 +235,8 @@ static void sim_scan( const rmd_program_t *dp, int seq, const char *sbuf, int sl
 int main( int argc, char **argv )
 {
 	try{
+		if( getenv( "HOSTSIM_BUDGET" ) )
+			hostsim_budget = std::max( 4, atoi( getenv( "HOSTSIM_BUDGET" ) ) );	// (rm_scan_core.h: at least 4)
 		rma::Args	args = rma::parse_args( argc, argv );
 		rma::Prepared	pr = rma::prepare( args );
 		fprintf( stderr, "%s: %d elements, %d searches, stride %d\n", args.dfname.c_str(),
@@ -242,6 +247,8 @@ int main( int argc, char **argv )
 			fprintf( stderr, "rmd_build: %s\n", err );
 			return 2;
 		}
+		if( hostsim_budget > 0 )
+			dp.step_budget = hostsim_budget;
 		int	stride = dp.hit_stride, n_cmp = rma_hit_efn_off( pr.prog.get() );
 		int64_t	total = 0, bad = 0, n_efn2 = 0;
 		int	seq = 0;
