@@ -2,6 +2,7 @@
 #include "rm_cli.h"
 #include "rm_score.h"
 #include "rm_efndata.h"
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -44,6 +45,12 @@ Prepared prepare( const Args &args )
 
 int cli_main( int argc, char **argv, BackendFactory make_backend )
 {
+	const auto	t_start = std::chrono::steady_clock::now();
+	auto lap = [&]( const char *what ){
+		if( getenv( "RNAMOTIF_TIMING" ) )
+			fprintf( stderr, "[timing] %-28s at %8.1f ms\n", what,
+				std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t_start ).count() );
+	};
 	try{
 		Args	args = parse_args( argc, argv );
 		if( args.vopt )				// rnamot.c:56-65
@@ -77,10 +84,13 @@ int cli_main( int argc, char **argv, BackendFactory make_backend )
 			d.score->dump( stderr );
 		if( args.copt )
 			return 0;
+		lap( "descriptor compiled" );
 		ScanBackend	be = make_backend( pr.prog.get(), pr.efn.get(), pr.efn2.get() );
+		lap( "scanner created" );
 		const char	*bb = getenv( "RNAMOTIF_BATCH_BASES" );
 		int64_t	batch_bases = bb ? atoll( bb ) : ( int64_t( 1 ) << 28 );
 		run_search( d, *pr.prog, be, stdout, batch_bases, nullptr );
+		lap( "search done" );
 		return 0;
 	}catch( Error &e ){
 		const char	*m = e.what();

@@ -2,7 +2,14 @@
 #include "rm_driver.h"
 #include "rm_score.h"
 #include "rm_pack.h"
+#include "rm_stream.h"
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 namespace rma {
 
@@ -43,10 +50,45 @@ static void revcomp( std::string &s )	// mk_rcmp, rnamot.c:193-216
 	s.swap( r );
 }
 
+// One candidate: restore what the search leaves in rm_descr[] at the end of the search list,
+// then find_ss :373-392 -- NAME COMP POS LEN, RM_score(), print_match().
+void Replayer::one_hit( const int32_t *w, const char *sid, const char *sdef, int slen, const char *sbuf, SearchStats &st )
+{
+	const int	ctx_off = rma_hit_ctx_off( &prog_ ), efn_off = rma_hit_efn_off( &prog_ );
+	const int	comp = w[ 1 ];
+	for( int e = 0; e < prog_.n_elems; e++ ){
+		Strel	&s = d_.descr[ e ];
+		s.matchoff = w[ RMA_HIT_HDR + 4 * e ];
+		s.matchlen = w[ RMA_HIT_HDR + 4 * e + 1 ];
+		s.n_mispairs = w[ RMA_HIT_HDR + 4 * e + 2 ];
+		s.n_mismatches = w[ RMA_HIT_HDR + 4 * e + 3 ];
+	}
+	if( d_.lctx ){
+		d_.lctx->matchoff = w[ ctx_off ];
+		d_.lctx->matchlen = w[ ctx_off + 1 ];
+	}
+	if( d_.rctx ){
+		d_.rctx->matchoff = w[ ctx_off + 2 ];
+		d_.rctx->matchlen = w[ ctx_off + 3 ];
+	}
+	d_.nval->pval = ( void * )sid;
+	d_.cval->ival = comp;
+	d_.pval->ival = comp ? slen - d_.descr[ 0 ].matchoff : d_.descr[ 0 ].matchoff + 1;
+	int	len = 0;
+	for( int e = 0; e < prog_.n_elems; e++ )
+		len += d_.descr[ e ].matchlen;
+	d_.lval->ival = len;
+	st.n_candidates++;
+	Ident	*h_id = nullptr;
+	if( d_.score->run( comp, slen, sbuf, &h_id, prog_.n_efn_sites ? w + efn_off : nullptr ) != SA_REJECT ){
+		printer_.print( sid, sdef, comp, slen, sbuf, h_id );
+		st.n_hits++;
+	}
+}
+
 void Replayer::replay( const std::vector<SeqRecord> &batch, const int32_t *hits, int64_t n, SearchStats &st )
 {
 	int	stride = rma_hit_stride( &prog_ );
-	int	ctx_off = rma_hit_ctx_off( &prog_ ), efn_off = rma_hit_efn_off( &prog_ );
 	int	cur_seq = -1;
 	std::string	rc;
 	for( int64_t h = 0; h < n; h++ ){
@@ -60,40 +102,191 @@ void Replayer::replay( const std::vector<SeqRecord> &batch, const int32_t *hits,
 			revcomp( rc );
 			cur_seq = seq;
 		}
-		const char	*sbuf = comp ? rc.c_str() : rec.seq.c_str();
-		int	slen = int( rec.seq.size() );
-		// restore what the search leaves in rm_descr[] at the end of the search list
-		for( int e = 0; e < prog_.n_elems; e++ ){
-			Strel	&s = d_.descr[ e ];
-			s.matchoff = w[ RMA_HIT_HDR + 4 * e ];
-			s.matchlen = w[ RMA_HIT_HDR + 4 * e + 1 ];
-			s.n_mispairs = w[ RMA_HIT_HDR + 4 * e + 2 ];
-			s.n_mismatches = w[ RMA_HIT_HDR + 4 * e + 3 ];
-		}
-		if( d_.lctx ){
-			d_.lctx->matchoff = w[ ctx_off ];
-			d_.lctx->matchlen = w[ ctx_off + 1 ];
-		}
-		if( d_.rctx ){
-			d_.rctx->matchoff = w[ ctx_off + 2 ];
-			d_.rctx->matchlen = w[ ctx_off + 3 ];
-		}
-		// find_ss, find_motif.c:373-392
-		d_.nval->pval = ( void * )rec.sid.c_str();
-		d_.cval->ival = comp;
-		d_.pval->ival = comp ? slen - d_.descr[ 0 ].matchoff : d_.descr[ 0 ].matchoff + 1;
-		int	len = 0;
-		for( int e = 0; e < prog_.n_elems; e++ )
-			len += d_.descr[ e ].matchlen;
-		d_.lval->ival = len;
-		st.n_candidates++;
-		Ident	*h_id = nullptr;
-		if( d_.score->run( comp, slen, sbuf, &h_id, prog_.n_efn_sites ? w + efn_off : nullptr ) != SA_REJECT ){
-			printer_.print( rec.sid.c_str(), rec.sdef.c_str(), comp, slen, sbuf, h_id );
-			st.n_hits++;
-		}
+		one_hit( w, rec.sid.c_str(), rec.sdef.c_str(), int( rec.seq.size() ), comp ? rc.c_str() : rec.seq.c_str(), st );
 	}
 }
+
+void Replayer::replay_packed( const PackFile &pk, int first, const int32_t *hits, int64_t n, SearchStats &st )
+{
+	const int	stride = rma_hit_stride( &prog_ ), ctx_off = rma_hit_ctx_off( &prog_ );
+	for( int64_t h = 0; h < n; h++ ){
+		const int32_t	*w = hits + h * stride;
+		const int	i = first + w[ 0 ];
+		if( w[ 0 ] < 0 || i >= pk.count() )
+			fail( "scanner returned a hit for sequence %d of a batch of %d.", w[ 0 ], pk.count() - first );
+		const int	slen = pk.slen[ i ];
+		// what the score program and print_match() read of the strand: the elements and the contexts
+		int	lo = slen, hi = 0;
+		auto span = [&]( int off, int len ){
+			if( len > 0 ){
+				lo = std::min( lo, off );
+				hi = std::max( hi, off + len );
+			}
+		};
+		for( int e = 0; e < prog_.n_elems; e++ )
+			span( w[ RMA_HIT_HDR + 4 * e ], w[ RMA_HIT_HDR + 4 * e + 1 ] );
+		if( d_.lctx )
+			span( w[ ctx_off ], w[ ctx_off + 1 ] );
+		if( d_.rctx )
+			span( w[ ctx_off + 2 ], w[ ctx_off + 3 ] );
+		if( text_.size() < size_t( slen ) + 1 )
+			text_.resize( size_t( slen ) + 1 + size_t( slen ) / 4 );
+		pk.window( i, w[ 1 ], lo, hi, text_.data() );
+		one_hit( w, pk.sid( i ), pk.sdef( i ), slen, text_.data(), st );
+	}
+}
+
+// ---------------------------------------------------------------- the pipelined search
+// Packed batches go through two more threads: one hands them to the scanner (upload, kernels,
+// copy back of the candidate records), one replays the candidates through the score program
+// and the printer -- in batch order, so the output is what the serial loop prints.  While a
+// batch is scanned the next one is being read and packed (rm_stream.cpp) and the one before is
+// being printed.  rnamot.c:158-185 is one loop; its three parts are all that it has.
+namespace {
+
+struct Batch {
+	std::unique_ptr<PackFile>	own;	// (a slice of a packed database on disk has no copy of its own)
+	const PackFile	*pk = nullptr;
+	int	first = 0, count = 0;
+	std::vector<int32_t>	hits;
+	int64_t	n_hits = 0;
+};
+
+class Pipeline {
+public:
+	Pipeline( ScanBackend &be, Replayer &rp, const rma_program_t &prog, SearchStats &st )
+		: be_( be ), rp_( rp ), prog_( prog ), st_( st )
+	{
+		gpu_ = std::thread( [ this ](){ gpu_loop(); } );
+		out_ = std::thread( [ this ](){ out_loop(); } );
+	}
+	~Pipeline()
+	{
+		{
+			std::lock_guard<std::mutex>	lk( mu_ );
+			closing_ = true;
+		}
+		cv_.notify_all();
+		gpu_.join();
+		out_.join();
+	}
+	void	submit( Batch &&b )
+	{
+		std::unique_lock<std::mutex>	lk( mu_ );
+		cv_.wait( lk, [ & ]{ return to_gpu_.size() < 2 || failed_; } );
+		rethrow( lk );
+		to_gpu_.push_back( std::move( b ) );
+		in_flight_++;
+		cv_.notify_all();
+	}
+	void	drain()			// every batch submitted so far is printed
+	{
+		std::unique_lock<std::mutex>	lk( mu_ );
+		cv_.wait( lk, [ & ]{ return in_flight_ == 0 || failed_; } );
+		rethrow( lk );
+	}
+private:
+	void	rethrow( std::unique_lock<std::mutex> & )
+	{
+		if( failed_ ){
+			failed_ = false;	// (reported once)
+			throw Error( what_ );
+		}
+	}
+	void	fail_with( const std::string &m )
+	{
+		std::lock_guard<std::mutex>	lk( mu_ );
+		if( !failed_ ){
+			failed_ = true;
+			what_ = m;
+		}
+		in_flight_ = 0;
+		to_gpu_.clear();
+		to_out_.clear();
+		cv_.notify_all();
+	}
+	void	gpu_loop()
+	{
+		for( ; ; ){
+			Batch	b;
+			{
+				std::unique_lock<std::mutex>	lk( mu_ );
+				cv_.wait( lk, [ & ]{ return !to_gpu_.empty() || closing_; } );
+				if( to_gpu_.empty() )
+					return;
+				b = std::move( to_gpu_.front() );
+				to_gpu_.pop_front();
+				cv_.notify_all();
+			}
+			char	err[ 1024 ] = "";
+			const int32_t	*hits = nullptr;
+			const auto	t0 = std::chrono::steady_clock::now();
+			if( be_.scan_packed( be_.self, b.pk, b.first, b.count, &hits, &b.n_hits, err, sizeof( err ) ) ){
+				fail_with( std::string( "scan failed: " ) + err );
+				continue;
+			}
+			b.hits.assign( hits, hits + b.n_hits * rma_hit_stride( &prog_ ) );	// (the scanner's buffer is its next scan's)
+			if( timing_ )
+				fprintf( stderr, "[timing] scan of %d entries: %.1f ms, %lld candidates\n", b.count,
+					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), ( long long )b.n_hits );
+			std::unique_lock<std::mutex>	lk( mu_ );
+			cv_.wait( lk, [ & ]{ return to_out_.size() < 2 || closing_; } );
+			to_out_.push_back( std::move( b ) );
+			cv_.notify_all();
+		}
+	}
+	void	out_loop()
+	{
+		for( ; ; ){
+			Batch	b;
+			{
+				std::unique_lock<std::mutex>	lk( mu_ );
+				cv_.wait( lk, [ & ]{ return !to_out_.empty() || ( closing_ && to_gpu_.empty() && in_flight_ == 0 ); } );
+				if( to_out_.empty() )
+					return;
+				b = std::move( to_out_.front() );
+				to_out_.pop_front();
+				cv_.notify_all();
+			}
+			const auto	t0 = std::chrono::steady_clock::now();
+			try{
+				rp_.replay_packed( *b.pk, b.first, b.hits.data(), b.n_hits, st_ );
+			}catch( Error &e ){
+				fail_with( e.what() );
+				continue;
+			}
+			if( timing_ )
+				fprintf( stderr, "[timing] replay of %lld candidates: %.1f ms\n", ( long long )b.n_hits,
+					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
+			std::lock_guard<std::mutex>	lk( mu_ );
+			if( in_flight_ > 0 )
+				in_flight_--;
+			cv_.notify_all();
+		}
+	}
+	ScanBackend	&be_;
+	Replayer	&rp_;
+	const rma_program_t	&prog_;
+	SearchStats	&st_;
+	std::mutex	mu_;
+	std::condition_variable	cv_;
+	std::deque<Batch>	to_gpu_, to_out_;
+	int	in_flight_ = 0;
+	bool	closing_ = false, failed_ = false;
+	const bool	timing_ = getenv( "RNAMOTIF_TIMING" ) != nullptr;
+	std::string	what_;
+	std::thread	gpu_, out_;
+};
+
+int parser_threads()
+{
+	if( const char *t = getenv( "RNAMOTIF_THREADS" ) )
+		return std::max( 1, atoi( t ) );
+	const unsigned	hw = std::thread::hardware_concurrency();
+	return int( std::max( 1u, std::min( 32u, hw > 3 ? hw - 2 : 1u ) ) );
+}
+
+}	// namespace
 
 int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE *out,
 	int64_t batch_bases, SearchStats *stats )
@@ -101,7 +294,6 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 	SearchStats	st;
 	Replayer	rp( d, prog, out );
 	rp.begin();
-	std::vector<FILE *>	files;
 	bool	use_stdin = d.args.dbfnames.empty();
 	size_t	nfiles = use_stdin ? 1 : d.args.dbfnames.size();
 	std::vector<SeqRecord>	batch;
@@ -109,9 +301,16 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 	char	err[ 1024 ];
 	int	ecnt = 0;
 	const int	show_progress = d.int_global( "show_progress", 0 );
+	// (RNAMOTIF_SERIAL: the one-thread loop over text, as the reference has it)
+	const bool	piped = be.scan_packed != nullptr && getenv( "RNAMOTIF_SERIAL" ) == nullptr;
+	std::unique_ptr<Pipeline>	pl;
+	if( piped )
+		pl.reset( new Pipeline( be, rp, prog, st ) );
 	auto flush = [&](){
 		if( batch.empty() )
 			return;
+		if( pl )
+			pl->drain();		// text batches are printed by this thread: after what is in flight
 		std::vector<const char *>	seqs;
 		std::vector<int32_t>	slens;
 		for( const SeqRecord &r : batch ){
@@ -127,12 +326,38 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		batch.clear();
 		in_batch = 0;
 	};
+	// rnamot.c:160-176: the entry counter, and show_progress's line every so many entries
+	auto tick = [&]( const char *sid ){
+		ecnt++;
+		if( show_progress > 0 && ecnt % show_progress == 0 )
+			fprintf( stderr, "%s: %7d: %s\n", d.args.argv0.c_str(), ecnt, sid );
+	};
+	auto submit = [&]( std::unique_ptr<PackFile> own, const PackFile *pk, int first, int count ){
+		int64_t	bases = 0;
+		for( int i = 0; i < count; i++ ){
+			tick( pk->sid( first + i ) );
+			bases += pk->slen[ first + i ];
+		}
+		st.n_seqs += count;
+		st.n_bases += bases;
+		Batch	b;
+		b.own = std::move( own );
+		b.pk = pk;
+		b.first = first;
+		b.count = count;
+		pl->submit( std::move( b ) );
+	};
 	// A packed database (rm_pack.h) takes the place of a text file: same entries, same order.
+	std::vector<std::unique_ptr<PackFile>>	packs;		// (alive until the last batch is printed)
 	auto scan_pack = [&]( const std::string &path ){
-		PackFile	pk;
+		packs.emplace_back( new PackFile );
+		PackFile	&pk = *packs.back();
 		std::string	perr;
+		const auto	t0 = std::chrono::steady_clock::now();
 		if( !pk.load( path, perr ) )
 			fail( "%s", perr.c_str() );
+		if( getenv( "RNAMOTIF_TIMING" ) )
+			fprintf( stderr, "[timing] pack loaded: %.1f ms\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
 		int	first = 0;
 		while( first < pk.count() ){
 			int	count = 0;
@@ -141,46 +366,32 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 				bases += pk.slen[ first + count ];
 				count++;
 			}
-			for( int i = 0; i < count; i++ ){
-				ecnt++;
-				if( show_progress > 0 && ecnt % show_progress == 0 )
-					fprintf( stderr, "%s: %7d: %s\n", d.args.argv0.c_str(), ecnt, pk.sid( first + i ) );
+			if( pl ){
+				submit( nullptr, &pk, first, count );
+				first += count;
+				continue;
 			}
+			// (a backend without a packed entry point: through text)
+			for( int i = 0; i < count; i++ )
+				tick( pk.sid( first + i ) );
 			st.n_seqs += count;
 			st.n_bases += bases;
+			std::vector<SeqRecord>	recs;
+			recs.resize( size_t( count ) );
+			std::vector<const char *>	seqs;
+			std::vector<int32_t>	slens;
+			for( int i = 0; i < count; i++ ){
+				recs[ i ].sid = pk.sid( first + i );
+				recs[ i ].sdef = pk.sdef( first + i );
+				recs[ i ].seq = pk.unpack( first + i );
+				seqs.push_back( recs[ i ].seq.c_str() );
+				slens.push_back( pk.slen[ first + i ] );
+			}
 			const int32_t	*hits = nullptr;
 			int64_t	n_hits = 0;
 			err[ 0 ] = '\0';
-			std::vector<SeqRecord>	recs;
-			recs.resize( size_t( count ) );
-			if( be.scan_packed != nullptr ){
-				if( be.scan_packed( be.self, &pk, first, count, &hits, &n_hits, err, sizeof( err ) ) )
-					fail( "scan failed: %s", err );
-			}else{
-				std::vector<const char *>	seqs;
-				std::vector<int32_t>	slens;
-				for( int i = 0; i < count; i++ ){
-					recs[ i ].seq = pk.unpack( first + i );
-					seqs.push_back( recs[ i ].seq.c_str() );
-					slens.push_back( pk.slen[ first + i ] );
-				}
-				if( be.scan( be.self, seqs.data(), slens.data(), count, &hits, &n_hits, err, sizeof( err ) ) )
-					fail( "scan failed: %s", err );
-			}
-			// text only for the entries that have candidates
-			const int	stride = rma_hit_stride( &prog );
-			for( int64_t h = 0; h < n_hits; h++ ){
-				const int	i = hits[ h * stride ];
-				if( i < 0 || i >= count )
-					fail( "scanner returned a hit for sequence %d of a batch of %d.", i, count );
-				SeqRecord	&r = recs[ i ];
-				if( r.sid.empty() ){
-					r.sid = pk.sid( first + i );
-					r.sdef = pk.sdef( first + i );
-					if( r.seq.empty() )
-						r.seq = pk.unpack( first + i );
-				}
-			}
+			if( be.scan( be.self, seqs.data(), slens.data(), count, &hits, &n_hits, err, sizeof( err ) ) )
+				fail( "scan failed: %s", err );
 			rp.replay( recs, hits, n_hits, st );
 			first += count;
 		}
@@ -194,6 +405,32 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 				ecnt++;		// the EOF that switches files is counted, rnamot.c:160-168
 			continue;
 		}
+		long	resume_at = 0;
+		if( !use_stdin && pl && seq_format_of( d.args.dbfmt ) == FMT_FASTN ){
+			// a FASTA file: read, packed and scanned in parallel as far as it is regular
+			FastaStream	fs;
+			if( fs.open( d.args.dbfnames[ f ], d.args.maxslen, parser_threads() ) ){
+				flush();
+				auto	t0 = std::chrono::steady_clock::now();
+				while( std::unique_ptr<PackFile> pk = fs.next( batch_bases ) ){
+					if( getenv( "RNAMOTIF_TIMING" ) ){
+						fprintf( stderr, "[timing] batch of %d entries read and packed: %.1f ms\n", pk->count(),
+							std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
+						t0 = std::chrono::steady_clock::now();
+					}
+					const PackFile	*p = pk.get();
+					submit( std::move( pk ), p, 0, p->count() );
+				}
+				if( fs.stopped_at() < 0 ){
+					// rnamot.c:160-176: the entry counter also ticks for the EOF that switches to
+					// the next file (with an empty name), not for the one that ends the run
+					if( f + 1 < nfiles )
+						tick( "" );
+					continue;
+				}
+				resume_at = long( fs.stopped_at() );	// an entry the reader has something to say about
+			}
+		}
 		if( !use_stdin ){
 			fp = fopen( d.args.dbfnames[ f ].c_str(), "r" );
 			if( fp == nullptr ){
@@ -201,18 +438,16 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 				fprintf( stderr, "DB_fnext: can't read seq file '%s'.\n", d.args.dbfnames[ f ].c_str() );
 				break;
 			}
+			if( resume_at > 0 )
+				fseek( fp, resume_at, SEEK_SET );
 		}
 		FastaReader	rd( fp, d.args.maxslen, seq_format_of( d.args.dbfmt ) );
 		SeqRecord	rec;
 		for( ; ; ){
 			const bool	got = rd.next( rec );
-			// rnamot.c:160-176: the entry counter also ticks for the EOF that switches to
-			// the next file (with an empty name), not for the one that ends the run
 			if( !got && ( use_stdin || f + 1 >= nfiles ) )
 				break;
-			ecnt++;
-			if( show_progress > 0 && ecnt % show_progress == 0 )
-				fprintf( stderr, "%s: %7d: %s\n", d.args.argv0.c_str(), ecnt, got ? rec.sid.c_str() : "" );
+			tick( got ? rec.sid.c_str() : "" );
 			if( !got )
 				break;
 			st.n_seqs++;
@@ -226,6 +461,10 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 			fclose( fp );
 	}
 	flush();
+	if( pl ){
+		pl->drain();
+		pl.reset();
+	}
 	rp.end();
 	if( stats )
 		*stats = st;

@@ -36,7 +36,13 @@ public:
 	void	end();			// END program, rnamot.c:187-188
 	// hits: n records of stride rma_hit_stride( prog ), sorted
 	void	replay( const std::vector<SeqRecord> &batch, const int32_t *hits, int64_t n, SearchStats &st );
+	// the same over entries first .. of a packed database (hit records count entries from first):
+	// the text of an entry is rebuilt for the span of each hit only (PackFile::window), so a batch
+	// of a hundred million bases with a few thousand hits costs a few thousand small windows
+	void	replay_packed( const PackFile &pk, int first, const int32_t *hits, int64_t n, SearchStats &st );
 private:
+	void	one_hit( const int32_t *w, const char *sid, const char *sdef, int slen, const char *sbuf, SearchStats &st );
+	std::vector<char>	text_;		// strand buffer of the entry in hand, filled window by window
 	Descriptor	&d_;
 	const rma_program_t	&prog_;
 	FILE	*out_;

@@ -40,6 +40,56 @@ void PackFile::add( const SeqRecord &rec )
 	text.push_back( '\0' );
 }
 
+void PackFile::append_packed( const std::string &sid, const std::string &sdef, const std::vector<uint32_t> &c,
+	const std::vector<uint32_t> &m, const std::vector<char> &x, int32_t n )
+{
+	base_off.push_back( int64_t( amask.size() ) * 32 );
+	exc_off.push_back( int64_t( exc.size() ) );
+	slen.push_back( n );
+	total_bases += n;
+	codes.insert( codes.end(), c.begin(), c.end() );
+	amask.insert( amask.end(), m.begin(), m.end() );
+	exc.insert( exc.end(), x.begin(), x.end() );
+	sid_off.push_back( int64_t( text.size() ) );
+	text.insert( text.end(), sid.c_str(), sid.c_str() + strlen( sid.c_str() ) + 1 );
+	sdef_off.push_back( int64_t( text.size() ) );
+	text.insert( text.end(), sdef.c_str(), sdef.c_str() + strlen( sdef.c_str() ) + 1 );
+}
+
+void PackFile::window( int i, int comp, int lo, int hi, char *out ) const
+{
+	const int	n = slen[ i ];
+	lo = lo < 0 ? 0 : lo;
+	hi = hi > n ? n : hi;
+	if( lo >= hi )
+		return;
+	const uint32_t	*cw = codes.data() + base_off[ i ] / 16;
+	const uint32_t	*mw = amask.data() + base_off[ i ] / 32;
+	if( comp ){
+		for( int p = lo; p < hi; p++ ){
+			const int	f = n - 1 - p;
+			out[ p ] = ( ( mw[ f >> 5 ] >> ( f & 31 ) ) & 1 ) ? 'n' : "tgca"[ ( cw[ f >> 4 ] >> ( 2 * ( f & 15 ) ) ) & 3 ];
+		}
+		return;
+	}
+	// the letters at masked positions come from exc[], in order: find the first one's index only
+	// if the window holds any
+	const char	*ex = nullptr;
+	for( int p = lo; p < hi; p++ ){
+		if( ( mw[ p >> 5 ] >> ( p & 31 ) ) & 1 ){
+			if( ex == nullptr ){
+				int64_t	before = 0;
+				for( int w = 0; w < ( p >> 5 ); w++ )
+					before += __builtin_popcount( mw[ w ] );
+				before += __builtin_popcount( mw[ p >> 5 ] & ( ( 1u << ( p & 31 ) ) - 1 ) );
+				ex = exc.data() + exc_off[ i ] + before;
+			}
+			out[ p ] = ex < exc.data() + exc.size() ? *ex++ : 'n';
+		}else
+			out[ p ] = "acgt"[ ( cw[ p >> 4 ] >> ( 2 * ( p & 15 ) ) ) & 3 ];
+	}
+}
+
 std::string PackFile::unpack( int i ) const
 {
 	const int	n = slen[ i ];

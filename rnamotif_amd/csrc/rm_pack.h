@@ -35,7 +35,15 @@ struct PackFile {
 	const char	*sid( int i ) const { return text.data() + sid_off[ i ]; }
 	const char	*sdef( int i ) const { return text.data() + sdef_off[ i ]; }
 	void	add( const SeqRecord &rec );
+	// an entry that is packed already (rm_stream.cpp): codes/amask hold 2 and 1 words per 32 bases
+	void	append_packed( const std::string &sid, const std::string &sdef, const std::vector<uint32_t> &codes,
+			const std::vector<uint32_t> &amask, const std::vector<char> &exc, int32_t slen );
 	std::string	unpack( int i ) const;		// the entry's sequence text
+	// Letters lo .. hi-1 of strand comp of entry i into out[ lo .. hi ): comp 0 the text as the
+	// readers deliver it, comp 1 its reverse complement with every letter that is not acgt an n
+	// (mk_rcmp, rnamot.c:193-216).  What print_match() and the score program read of an entry is
+	// the span of a hit, not the entry.
+	void	window( int i, int comp, int lo, int hi, char *out ) const;
 	bool	save( const std::string &path, std::string &err ) const;
 	bool	load( const std::string &path, std::string &err );
 	static bool	is_pack( const std::string &path );

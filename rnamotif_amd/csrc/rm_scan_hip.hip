@@ -1260,7 +1260,10 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	const char	*tt = getenv( "RNAMOTIF_TILE" );
 	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 16384 )
 		sc->tile_t = atoi( tt );
-	sc->hit_cap = 1 << 20;
+	// room for the candidates of a few hundred Mbase at the densities of the reference's descriptors
+	// (63 per Mbase for trna.descr); a scan that finds more is repeated into a buffer of the right
+	// size (count-then-emit, rma_scan_device)
+	sc->hit_cap = 1 << 17;
 	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
 	*out = sc;
 	return 0;

@@ -1,0 +1,178 @@
+"""GPU: the product command line program (rnamotif_amd/bin/rnamotif, HIP scanner behind the C ABI)
+through the database input modes of the reference's main loop (/root/reference/src/rnamot.c:
+158-185, DB_fnext dbutil.c:12-40, FN_/PIR_/GB_fgetseq dbutil.c:42,130,226): several files with
+the EOF fall-through, stdin, -N, -fmt pir|gb, show_progress, a packed database -- each against the
+test-only oracle CLI (same host front end, scalar CPU scan) byte for byte, stdout and stderr.
+The product reads regular FASTA files through its parallel path (rm_stream.cpp) and everything
+else through the serial reader; RNAMOTIF_SERIAL=1 forces the latter, and both must print the same.
+Also: how long the whole program takes from text and from a pack (timed, with a floor)."""
+import hashlib
+import os
+import subprocess
+import time
+
+import pytest
+
+import pins
+import rnamotif_amd as R
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENV = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+
+
+def _run(exe, workdir, args, stdin=None, env=None, timeout=900):
+    p = subprocess.run([exe] + args, cwd=workdir, env=dict(ENV, **(env or {})), input=stdin,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    # (show_progress lines start with argv[0], rnamot.c:172)
+    return p.returncode, p.stdout, p.stderr.replace(exe.encode() + b":", b"rnamotif:")
+
+
+def _both(built, workdir, args, stdin=None, env=None):
+    """product (parallel path), product (serial path), oracle: all three the same"""
+    want = _run(built["oracle_cli"], workdir, args, stdin, env)
+    got = _run(built["cli"], workdir, args, stdin, env)
+    ser = _run(built["cli"], workdir, args, stdin, dict(env or {}, RNAMOTIF_SERIAL="1"))
+    assert got[0] == want[0] and ser[0] == want[0], (got[2][-300:], want[2][-300:])
+    assert got[1] == want[1], "stdout of the product differs from the oracle CLI's"
+    assert ser[1] == want[1], "stdout of the product (serial reader) differs from the oracle CLI's"
+    # stderr: same lines (the progress lines of the pipelined path are printed when a batch is
+    # handed over, not entry by entry between hits -- their order among themselves is the same)
+    assert sorted(got[2].split(b"\n")) == sorted(want[2].split(b"\n")), (got[2][-400:], want[2][-400:])
+    assert ser[2] == want[2]
+    return want
+
+
+def _records(gbrna, n=600):
+    return R.read_fasta(gbrna)[:n]
+
+
+def _fasta(recs, width=70):
+    out = []
+    for sid, sdef, seq in recs:
+        out.append(b">" + sid + (b" " + sdef if sdef else b"") + b"\n")
+        s = seq.upper()
+        out.extend(s[i:i + width] + b"\n" for i in range(0, len(s), width))
+    return b"".join(out)
+
+
+def test_parallel_and_serial_reader_print_the_pins(built, workdir):
+    """the whole test database: parallel path == serial path == the reference's pinned stdout"""
+    for name in ("trna.efn.descr", "getbest.descr", "pk1.descr"):
+        rc, out, err = _run(built["cli"], workdir, ["-descr", name, "gbrna.111.0.fastn"])
+        rc2, out2, err2 = _run(built["cli"], workdir, ["-descr", name, "gbrna.111.0.fastn"], env={"RNAMOTIF_SERIAL": "1"})
+        rc3, out3, _ = _run(built["cli"], workdir, ["-descr", name, "gbrna.111.0.fastn"], env={"RNAMOTIF_BATCH_BASES": "50000", "RNAMOTIF_THREADS": "5"})
+        assert rc == 0 and rc2 == 0 and rc3 == 0, err
+        assert hashlib.md5(out).hexdigest() == pins.SLACK[name][1]
+        assert out2 == out and out3 == out and err2 == err
+
+
+def test_several_files_stdin_and_eof_fall_through(built, workdir, gbrna, tmp_path):
+    recs = _records(gbrna)
+    a, b, c = tmp_path / "a.fastn", tmp_path / "b.fastn", tmp_path / "c.fastn"
+    a.write_bytes(_fasta(recs[:200]))
+    b.write_bytes(_fasta(recs[200:230]))
+    c.write_bytes(_fasta(recs[230:]))
+    whole = _fasta(recs)
+    w = _both(built, workdir, ["-descr", "trna.descr", "-Dshow_progress=97", str(a), str(b), str(c)])
+    assert w[1].count(b"\n>") > 20
+    # the EOF that switches files counts as an entry (rnamot.c:160-168): with 3 files the progress
+    # lines fall on other entries than with one file
+    one = tmp_path / "one.fastn"
+    one.write_bytes(whole)
+    w1 = _both(built, workdir, ["-descr", "trna.descr", "-Dshow_progress=97", str(one)])
+    assert w1[1] == w[1] and w1[2] != w[2]
+    # stdin
+    w2 = _both(built, workdir, ["-descr", "trna.descr", "-Dshow_progress=97"], stdin=whole)
+    assert w2[1] == w[1]
+    # a file that cannot be read ends the run there (DB_fnext, dbutil.c:33-37)
+    _both(built, workdir, ["-descr", "trna.descr", str(a), str(tmp_path / "missing.fastn"), str(c)])
+
+
+def test_maxslen_truncation_and_irregular_entries(built, workdir, gbrna, tmp_path):
+    recs = _records(gbrna, 80)
+    fa = tmp_path / "r.fastn"
+    fa.write_bytes(_fasta(recs))
+    w = _both(built, workdir, ["-descr", "trna.descr", "-N", "300", str(fa)])
+    assert w[2].count(b"truncated to 300") == sum(1 for r in recs if len(r[2]) > 300)
+    # entries the parallel path hands to the serial reader: '>' in a definition line and in the
+    # middle of a line, an over-long definition line, an unnamed entry that ends the file
+    odd = tmp_path / "odd.fastn"
+    body = _fasta(recs[:20]) + b">x1 def > with >signs\n" + recs[20][2] + b"\n" + recs[21][2][:50] + b">mid line\n" + recs[21][2] + b"\n"
+    body += b">longdef " + b"d" * 21000 + b"\n" + recs[22][2] + b"\n" + _fasta(recs[23:40]) + b">\n" + recs[41][2] + b"\n" + _fasta(recs[42:50])
+    odd.write_bytes(body)
+    w = _both(built, workdir, ["-descr", "trna.descr", str(odd)])
+    assert b"def len" in w[2] and b"unnamed entry" in w[2]
+
+
+def test_pir_and_genbank(built, workdir, gbrna, tmp_path):
+    recs = _records(gbrna, 300)
+    pir = tmp_path / "r.pir"
+    pir.write_bytes(b"".join(b">" + sid + b"\n" + (sdef or b" ") + b"\n" + seq.upper() + b"*\n" for sid, sdef, seq in recs))
+    w = _both(built, workdir, ["-descr", "trna.descr", "-fmt", "pir", str(pir)])
+    assert w[1].count(b"\n>") > 10
+    gb = tmp_path / "r.gb"
+    out = []
+    for sid, sdef, seq in recs:
+        if sid.count(b"|") != 4:
+            continue
+        _, gid, _, acc, locus = sid.split(b"|")
+        lines = [b"LOCUS       " + locus + b"   %d bp    RNA" % len(seq), b"DEFINITION  " + sdef + b".", b"ACCESSION   " + acc,
+                 b"VERSION     " + acc + b".1  GI:" + gid, b"ORIGIN      "]
+        for i in range(0, len(seq), 60):
+            chunk = seq[i:i + 60]
+            lines.append(b"%9d " % (i + 1) + b" ".join(chunk[j:j + 10] for j in range(0, len(chunk), 10)))
+        lines.append(b"//")
+        out.append(b"\n".join(lines) + b"\n")
+    gb.write_bytes(b"".join(out))
+    w = _both(built, workdir, ["-descr", "trna.descr", "-fmt", "gb", str(gb)])
+    assert w[1].count(b"\n>") > 5
+
+
+def test_pack_and_text_mixed(built, workdir, gbrna, tmp_path):
+    recs = _records(gbrna)
+    a, c = tmp_path / "a.fastn", tmp_path / "c.fastn"
+    a.write_bytes(_fasta(recs[:250]))
+    c.write_bytes(_fasta(recs[400:]))
+    bpk = tmp_path / "b.rmpk"
+    R.Pack.write(str(bpk), recs[250:400])
+    whole = tmp_path / "w.fastn"
+    whole.write_bytes(_fasta(recs))
+    want = _run(built["oracle_cli"], workdir, ["-descr", "getbest.descr", str(whole)])
+    for env in ({}, {"RNAMOTIF_SERIAL": "1"}, {"RNAMOTIF_BATCH_BASES": "20000"}):
+        got = _run(built["cli"], workdir, ["-descr", "getbest.descr", str(a), str(bpk), str(c)], env=env)
+        assert got[0] == 0 and got[1] == want[1], env
+
+
+def test_whole_program_throughput(built, workdir, tmp_path):
+    """`rnamotif -descr trna.descr syn.fastn` from text and from a pack, 200 Mbase here (the 1 Gbase
+    figures are in DESIGN.md section 6): identical output, and a floor on the search -- reading or
+    loading, packing, upload, scan, copy back, score program and printing, i.e. the program without
+    process start, HIP initialisation (0.1-0.25 s on the test boxes, not ours to shorten) and exit --
+    that a one-thread reader does not reach."""
+    import re
+    fa = str(tmp_path / "syn200M.fastn")
+    R.write_synthetic_fasta(fa, 200)
+    pk = str(tmp_path / "syn200M.rmpk")
+    pack_tool = os.path.join(ROOT, "rnamotif_amd", "bin", "rnamotif_pack")
+    subprocess.run([pack_tool, pk, fa], check=True, timeout=900)
+    res = {}
+    for what, args, env in (("text", [fa], {}), ("text, one thread", [fa], {"RNAMOTIF_SERIAL": "1"}), ("pack", [pk], {})):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc, out, err = _run(built["cli"], workdir, ["-descr", "trna.efn.descr"] + args,
+                                env=dict(env, RNAMOTIF_TIMING="1", RNAMOTIF_BATCH_BASES="64000000"))
+            dt = time.perf_counter() - t0
+            assert rc == 0, err
+            at = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(rb"\[timing\] ([a-z ]+?) +at +([0-9.]+) ms", err)}
+            search = (at[b"search done"] - at[b"scanner created"]) * 1e-3
+            if best is None or search < best[0]:
+                best = (search, dt)
+        res[what] = best + (hashlib.md5(out).hexdigest(), out.count(b"\n>"))
+    print("\n200 Mbase:", {k: "search %.3f s = %.2f Gbases/s, whole program %.2f s" % (v[0], 0.2 / v[0], v[1]) for k, v in res.items()})
+    assert len({v[2] for v in res.values()}) == 1 and res["text"][3] > 10000
+    assert 0.2 / res["text"][0] >= 1.5, res
+    assert 0.2 / res["pack"][0] >= 1.5, res
+    assert res["text"][0] < res["text, one thread"][0]

@@ -16,12 +16,12 @@ def hostsim():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     srcs = [os.path.join(ROOT, "tests", "hostsim", "hostsim_check.cpp")]
     srcs += [os.path.join(H, f) for f in ("rm_regex.cpp", "rm_compile.cpp", "rm_parse.cpp", "rm_score.cpp",
-                                          "rm_efndata.cpp", "rm_efn2data.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp", "rm_dump.cpp", "rm_pack.cpp",
+                                          "rm_efndata.cpp", "rm_efn2data.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp", "rm_dump.cpp", "rm_pack.cpp", "rm_stream.cpp",
                                           "rm_dev_program.cpp")]
     srcs += [os.path.join(ROOT, "oracle", f) for f in ("rm_oracle_scan.c", "rm_oracle_efn.c", "rm_oracle_efn2.c")]
     newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(H, "rm_scan_core.h")])
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < newest:
-        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + H,
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + H,
                         "-I" + os.path.join(ROOT, "oracle"), "-o", BIN] + srcs + ["-lm"], check=True)
     return BIN
 
