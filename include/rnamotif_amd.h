@@ -98,6 +98,18 @@ int	rma_pack_seq( const rma_pack_t *pk, int32_t i, char *buf );
 /* entries [first, first+count) straight into HBM; hit records count entries from first */
 int	rma_db_create_packed( rma_scanner_t *sc, const rma_pack_t *pk, int32_t first, int32_t count,
 		rma_db_t **out, char *err, size_t errlen );
+/* The same database in memory, read from sequence files the way rnamotif reads them (DB_fnext,
+ * dbutil.c:12-40; fmt "fastn" | "pir" | "gb" or NULL; maxslen = rnamotif's -N, 0 for its default):
+ * FASTA files through the parallel reader, everything else -- and every entry a reader has a
+ * diagnostic for -- through the restatements of FN_/PIR_/GB_fgetseq, which print what the
+ * reference prints.  Files that are packed databases already are appended as they are. */
+int	rma_pack_read( const char *const *paths, int32_t n_paths, const char *fmt, int32_t maxslen, int32_t threads,
+		rma_pack_t **out, char *err, size_t errlen );
+/* Any n entries of a packed database, entry[i] with start positions pos_lo[i] <= szero < pos_hi[i]
+ * (NULL: all), straight into HBM: what one rank of a multi-GPU search takes of a database every
+ * rank has read.  Hit records number the entries 0 .. n-1 in the order given. */
+int	rma_db_create_packed_ranges( rma_scanner_t *sc, const rma_pack_t *pk, const int32_t *entry,
+		const int32_t *pos_lo, const int32_t *pos_hi, int32_t n, rma_db_t **out, char *err, size_t errlen );
 
 /* ---- scan every sequence of db (both strands when the program says so).
  * *hits receives *n_hits records of rma_hit_stride( prog ) words, sorted by
@@ -119,6 +131,10 @@ int	rma_replay_open( rma_descr_t *d, const char *path, rma_replay_t **out, char 
 /* one batch: the same sequences (ids, definition lines, text) the db was made from */
 int	rma_replay_batch( rma_replay_t *rp, const char *const *sids, const char *const *sdefs,
 		const char *const *seqs, const int32_t *slens, int32_t n,
+		const int32_t *hits, int64_t n_hits, int64_t *n_printed, char *err, size_t errlen );
+/* the same over a packed database: word 0 of a record is the entry's number in pk minus first; the
+ * text of an entry is rebuilt for the span of each hit only */
+int	rma_replay_pack( rma_replay_t *rp, const rma_pack_t *pk, int32_t first,
 		const int32_t *hits, int64_t n_hits, int64_t *n_printed, char *err, size_t errlen );
 int	rma_replay_close( rma_replay_t *rp, char *err, size_t errlen );	/* runs the END program */
 

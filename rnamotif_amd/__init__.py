@@ -70,6 +70,9 @@ def lib() -> C.CDLL:
     L.rma_db_create_ranges.argtypes = [vp, cpp, i32p, i32p, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_db_create_packed.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_pack_write.argtypes = [C.c_char_p, cpp, cpp, cpp, i32p, C.c_int32, C.c_char_p, C.c_size_t]
+    L.rma_pack_read.argtypes = [cpp, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_db_create_packed_ranges.argtypes = [vp, vp, i32p, i32p, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_replay_pack.argtypes = [vp, vp, C.c_int32, i32p, C.c_int64, i64p, C.c_char_p, C.c_size_t]
     L.rma_pack_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_pack_close.argtypes = [vp]
     L.rma_pack_count.argtypes = [vp]
@@ -157,12 +160,22 @@ class Database:
     """Sequences packed 2 bit + ambiguity mask, resident in HBM."""
 
     def __init__(self, scanner: "Scanner", seqs: Optional[Sequence[bytes]] = None, pack: Optional["Pack"] = None,
-                 first: int = 0, count: Optional[int] = None, ranges: Optional[Sequence[Tuple[int, int]]] = None):
+                 first: int = 0, count: Optional[int] = None, ranges: Optional[Sequence[Tuple[int, int]]] = None,
+                 entries: Optional[Sequence[int]] = None):
         L = lib()
         self.scanner = scanner
         h = C.c_void_p()
         err = C.create_string_buffer(_ERRLEN)
-        if pack is not None:
+        if pack is not None and entries is not None:
+            # any entries of a packed database, each with a range of start positions (rma_db_create_packed_ranges)
+            n = len(entries)
+            assert ranges is None or len(ranges) == n
+            self.n_seqs = n
+            ent = (C.c_int32 * max(n, 1))(*[int(e) for e in entries])
+            lo = (C.c_int32 * max(n, 1))(*[int(r[0]) for r in ranges]) if ranges is not None else None
+            hi = (C.c_int32 * max(n, 1))(*[int(r[1]) for r in ranges]) if ranges is not None else None
+            _check(L.rma_db_create_packed_ranges(scanner._h, pack._h, ent, lo, hi, n, C.byref(h), err, _ERRLEN), err)
+        elif pack is not None:
             # entries [first, first+count) of a packed database, uploaded as they are
             count = pack.count - first if count is None else count
             self.n_seqs = count
@@ -209,8 +222,10 @@ class Scanner:
     def database(self, seqs: Sequence[bytes], ranges: Optional[Sequence[Tuple[int, int]]] = None) -> Database:
         return Database(self, seqs, ranges=ranges)
 
-    def database_from_pack(self, pack: "Pack", first: int = 0, count: Optional[int] = None) -> Database:
-        return Database(self, pack=pack, first=first, count=count)
+    def database_from_pack(self, pack: "Pack", first: int = 0, count: Optional[int] = None,
+                           entries: Optional[Sequence[int]] = None,
+                           ranges: Optional[Sequence[Tuple[int, int]]] = None) -> Database:
+        return Database(self, pack=pack, first=first, count=count, entries=entries, ranges=ranges)
 
     def scan(self, db: Database, copy: bool = True) -> np.ndarray:
         """All candidates of db in reference order: int32 array [n, hit_stride].  With
@@ -270,6 +285,16 @@ class Replay:
                                   C.byref(printed), err, _ERRLEN), err)
         return printed.value
 
+    def pack(self, pack: "Pack", hits: np.ndarray, first: int = 0) -> int:
+        """Candidates over a packed database (word 0 of a record: entry number minus first)."""
+        L = lib()
+        hits = np.ascontiguousarray(hits, dtype=np.int32)
+        printed = C.c_int64()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_replay_pack(self._h, pack._h, first, hits.ctypes.data_as(C.POINTER(C.c_int32)), hits.shape[0],
+                                 C.byref(printed), err, _ERRLEN), err)
+        return printed.value
+
     def close(self) -> None:
         if self._h:
             err = C.create_string_buffer(_ERRLEN)
@@ -310,14 +335,30 @@ class Pack:
     """A packed database on disk (rma_pack_*): what the readers deliver, in the
     layout the scanner keeps in HBM."""
 
-    def __init__(self, path: str):
+    def __init__(self, path: Optional[str] = None, _handle=None):
         L = lib()
-        h = C.c_void_p()
-        err = C.create_string_buffer(_ERRLEN)
-        _check(L.rma_pack_open(path.encode(), C.byref(h), err, _ERRLEN), err)
+        h = _handle if _handle is not None else C.c_void_p()
+        if _handle is None:
+            err = C.create_string_buffer(_ERRLEN)
+            _check(L.rma_pack_open(path.encode(), C.byref(h), err, _ERRLEN), err)
         self._h = h
         self.count = int(L.rma_pack_count(h))
         self.bases = int(L.rma_pack_bases(h))
+
+    @staticmethod
+    def read(paths: Sequence[str], fmt: str = "", maxslen: int = 0, threads: int = 0) -> "Pack":
+        """Sequence files (or packed databases) read the way rnamotif reads them, into memory
+        (rma_pack_read): -fmt, -N and every quirk of the reference's readers included."""
+        L = lib()
+        h = C.c_void_p()
+        err = C.create_string_buffer(_ERRLEN)
+        arr = _cstr_array([p.encode() for p in paths])
+        _check(L.rma_pack_read(arr, len(paths), fmt.encode() if fmt else None, maxslen, threads, C.byref(h), err, _ERRLEN), err)
+        return Pack(_handle=h)
+
+    def lengths(self) -> List[int]:
+        L = lib()
+        return [int(L.rma_pack_slen(self._h, i)) for i in range(self.count)]
 
     @staticmethod
     def write(path: str, records: Sequence[Tuple[bytes, bytes, bytes]]) -> None:

@@ -5,6 +5,7 @@
 #include "rm_cli.h"
 #include "rm_efndata.h"
 #include "rm_pack.h"
+#include "rm_stream.h"
 #include <cctype>
 #include <cstddef>
 #include <cstring>
@@ -122,6 +123,25 @@ extern "C" int rma_replay_batch( rma_replay_t *rp, const char *const *sids, cons
 	}
 }
 
+struct rma_pack {
+	rma::PackFile	pf;
+};
+
+extern "C" int rma_replay_pack( rma_replay_t *rp, const rma_pack_t *pk, int32_t first,
+	const int32_t *hits, int64_t n_hits, int64_t *n_printed, char *err, size_t errlen )
+{
+	try{
+		int64_t	before = rp->st.n_hits;
+		rp->rp->replay_packed( pk->pf, first, hits, n_hits, rp->st );
+		if( n_printed )
+			*n_printed = rp->st.n_hits - before;
+		fflush( rp->fp );
+		return 0;
+	}catch( rma::Error &e ){
+		return set_err( err, errlen, e.what() );
+	}
+}
+
 extern "C" int rma_replay_close( rma_replay_t *rp, char *err, size_t errlen )
 {
 	int	rv = 0;
@@ -139,10 +159,6 @@ extern "C" int rma_replay_close( rma_replay_t *rp, char *err, size_t errlen )
 }
 
 // ---------------------------------------------------------------- packed database
-
-struct rma_pack {
-	rma::PackFile	pf;
-};
 
 extern "C" int rma_pack_write( const char *path, const char *const *sids, const char *const *sdefs,
 	const char *const *seqs, const int32_t *slens, int32_t n, char *err, size_t errlen )
@@ -174,6 +190,71 @@ extern "C" int rma_pack_open( const char *path, rma_pack_t **out, char *err, siz
 	if( !pk->pf.load( path, e ) ){
 		delete pk;
 		return set_err( err, errlen, e.c_str() );
+	}
+	*out = pk;
+	return 0;
+}
+
+extern "C" int rma_pack_read( const char *const *paths, int32_t n_paths, const char *fmt, int32_t maxslen, int32_t threads,
+	rma_pack_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	rma_pack	*pk = new rma_pack;
+	const int	lim = maxslen > 0 ? maxslen + 1 : 30000000 + 1;		// getargs.c: -N n reads n letters
+	const rma::SeqFormat	sf = rma::seq_format_of( fmt ? fmt : "" );
+	for( int f = 0; f < n_paths; f++ ){
+		const std::string	path = paths[ f ];
+		if( rma::PackFile::is_pack( path ) ){
+			rma::PackFile	one;
+			std::string	e;
+			if( !one.load( path, e ) ){
+				delete pk;
+				return set_err( err, errlen, e.c_str() );
+			}
+			for( int i = 0; i < one.count(); i++ ){
+				const int64_t	w1 = one.base_off[ i ] / 32, nw1 = ( int64_t( one.slen[ i ] ) + 31 ) / 32;
+				const int64_t	x0 = one.exc_off[ i ], x1 = i + 1 < one.count() ? one.exc_off[ i + 1 ] : int64_t( one.exc.size() );
+				pk->pf.append_packed( one.sid( i ), one.sdef( i ),
+					std::vector<uint32_t>( one.codes.begin() + 2 * w1, one.codes.begin() + 2 * ( w1 + nw1 ) ),
+					std::vector<uint32_t>( one.amask.begin() + w1, one.amask.begin() + w1 + nw1 ),
+					std::vector<char>( one.exc.begin() + x0, one.exc.begin() + x1 ), one.slen[ i ] );
+			}
+			continue;
+		}
+		long	resume_at = 0;
+		if( sf == rma::FMT_FASTN ){
+			rma::FastaStream	fs;
+			if( fs.open( path, lim, threads > 0 ? threads : 8 ) ){
+				while( std::unique_ptr<rma::PackFile> b = fs.next( int64_t( 1 ) << 40 ) ){
+					if( pk->pf.count() == 0 )
+						pk->pf = std::move( *b );
+					else for( int i = 0; i < b->count(); i++ ){
+						const int64_t	w1 = b->base_off[ i ] / 32, nw1 = ( int64_t( b->slen[ i ] ) + 31 ) / 32;
+						const int64_t	x0 = b->exc_off[ i ], x1 = i + 1 < b->count() ? b->exc_off[ i + 1 ] : int64_t( b->exc.size() );
+						pk->pf.append_packed( b->sid( i ), b->sdef( i ),
+							std::vector<uint32_t>( b->codes.begin() + 2 * w1, b->codes.begin() + 2 * ( w1 + nw1 ) ),
+							std::vector<uint32_t>( b->amask.begin() + w1, b->amask.begin() + w1 + nw1 ),
+							std::vector<char>( b->exc.begin() + x0, b->exc.begin() + x1 ), b->slen[ i ] );
+					}
+				}
+				if( fs.stopped_at() < 0 )
+					continue;
+				resume_at = long( fs.stopped_at() );
+			}
+		}
+		FILE	*fp = fopen( path.c_str(), "r" );
+		if( fp == nullptr ){
+			// DB_fnext, dbutil.c:33-37: report and stop reading
+			fprintf( stderr, "DB_fnext: can't read seq file '%s'.\n", path.c_str() );
+			break;
+		}
+		if( resume_at > 0 )
+			fseek( fp, resume_at, SEEK_SET );
+		rma::FastaReader	rd( fp, lim, sf );
+		rma::SeqRecord	rec;
+		while( rd.next( rec ) )
+			pk->pf.add( rec );
+		fclose( fp );
 	}
 	*out = pk;
 	return 0;

@@ -1443,6 +1443,31 @@ extern "C" int rma_db_create_packed( rma_scanner_t *sc, const rma_pack_t *pack, 
 		size_t( ( b1 - b0 ) / 32 ), rel.data(), pf.slen.data() + first, count, out, err, errlen );
 }
 
+extern "C" int rma_db_create_packed_ranges( rma_scanner_t *sc, const rma_pack_t *pack, const int32_t *entry,
+	const int32_t *pos_lo, const int32_t *pos_hi, int32_t n, rma_db_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	const rma::PackFile	&pf = *rma_pack_file( pack );
+	// the chosen entries side by side (every entry starts on a 32-base boundary: whole words)
+	std::vector<uint32_t>	codes, amask;
+	std::vector<int64_t>	rel( size_t( std::max( n, 0 ) ) );
+	std::vector<int32_t>	slen( size_t( std::max( n, 0 ) ) );
+	for( int i = 0; i < n; i++ ){
+		const int	e = entry[ i ];
+		if( e < 0 || e >= pf.count() ){
+			snprintf( err, errlen, "entry %d is outside the packed database (%d entries)", e, pf.count() );
+			return 1;
+		}
+		const int64_t	w1 = pf.base_off[ e ] / 32, nw1 = ( int64_t( pf.slen[ e ] ) + 31 ) / 32;
+		rel[ i ] = int64_t( amask.size() ) * 32;
+		slen[ i ] = pf.slen[ e ];
+		codes.insert( codes.end(), pf.codes.begin() + 2 * w1, pf.codes.begin() + 2 * ( w1 + nw1 ) );
+		amask.insert( amask.end(), pf.amask.begin() + w1, pf.amask.begin() + w1 + nw1 );
+	}
+	return db_upload( sc, codes.data(), codes.size(), amask.data(), amask.size(), rel.data(), slen.data(), n, out, err, errlen,
+		pos_lo, pos_hi );
+}
+
 extern "C" void rma_db_destroy( rma_db_t *db )
 {
 	if( db == nullptr )

@@ -60,6 +60,33 @@ def partition_ranges(lengths: Sequence[int], world: int, max_chunk: int = 0) -> 
     return parts
 
 
+def all_ok(ok: bool, device=None) -> bool:
+    """True on every rank iff every rank passes True: one MIN all-reduce.  A rank that fails
+    before the gather (no scanner, no memory, a bad file) says so here instead of leaving the
+    others waiting in a collective; every rank then leaves with an error of its own."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return ok
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if device is not None else torch.device("cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+_send_cache = {}
+
+
+def _staging(device, words: int):
+    """A device buffer for the records on their way out (reused: no allocation per step)."""
+    import torch
+    key = str(device)
+    buf = _send_cache.get(key)
+    if buf is None or buf.numel() < words:
+        buf = torch.empty(max(words, 1 << 16), dtype=torch.int32, device=device)
+        _send_cache[key] = buf
+    return buf
+
+
 def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int, device=None,
                 concat: bool = True):
     """Gather int32 hit records [n, stride] from every rank to rank 0.
@@ -71,37 +98,41 @@ def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int
     concat=False rank 0 gets the per-rank arrays (each in order, in rank order) as a
     list instead: when the ranks hold consecutive runs of entries that list *is* the
     ordered hit stream and a consumer can walk it without the copy.
+
+    Two collectives per call: an all-gather of the counts (8 bytes per rank) and one gather of
+    the records padded to the largest count -- KBs to a few MB, far below what a link carries in
+    the time of a scan step; no send/receive per rank, one host synchronisation (the counts).
     """
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(), dist.get_rank()
-    h = np.ascontiguousarray(local_hits, dtype=np.int32).reshape(-1, stride).copy()
-    if h.shape[0]:
-        h[:, 0] = np.asarray(global_index, dtype=np.int32)[h[:, 0]]
+    h = np.ascontiguousarray(local_hits, dtype=np.int32).reshape(-1, stride)
     dev = device if device is not None else torch.device("cpu")
-    # one collective for the counts, one host sync
     n = torch.tensor([h.shape[0]], dtype=torch.int64, device=dev)
     all_n = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_n, n)
     counts = [int(c) for c in all_n.tolist()]
+    most = max(counts)
+    if most == 0:
+        empty = np.zeros((0, stride), dtype=np.int32)
+        return (empty if concat else ([empty] * world if rank == 0 else []))
+    # the records, entry numbers made database-wide, padded to the largest count, on the device
+    mine = _staging(dev, most * stride)[: most * stride].view(most, stride)
+    if h.shape[0]:
+        src = torch.from_numpy(h)
+        mine[: h.shape[0]].copy_(src, non_blocking=True)
+        idx = torch.as_tensor(np.asarray(global_index, dtype=np.int32), device=dev)
+        mine[: h.shape[0], 0] = idx[mine[: h.shape[0], 0].long()]
     if rank == 0:
-        # post every receive, then wait: the transfers of the ranks overlap (xGMI is point to point)
-        bufs, reqs = {}, []
-        for r in range(1, world):
-            if counts[r] == 0:
-                continue
-            bufs[r] = torch.empty((counts[r], stride), dtype=torch.int32, device=dev)
-            reqs.append(dist.irecv(bufs[r], src=r))
-        for q in reqs:
-            q.wait()
-        parts = [h] + [bufs[r].cpu().numpy() for r in sorted(bufs)]
+        bufs = [torch.empty((most, stride), dtype=torch.int32, device=dev) for _ in range(world)]
+        dist.gather(mine, gather_list=bufs, dst=0)
+        parts = [bufs[r][: counts[r]].cpu().numpy() for r in range(world)]
         if not concat:
             return parts
-        allh = np.concatenate(parts, axis=0) if len(parts) > 1 else h
+        allh = np.concatenate(parts, axis=0)
         return sort_hits(allh)
-    if h.shape[0]:
-        dist.send(torch.from_numpy(h).to(dev), dst=0)
+    dist.gather(mine, gather_list=None, dst=0)
     return np.zeros((0, stride), dtype=np.int32) if concat else []
 
 

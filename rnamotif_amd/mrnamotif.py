@@ -3,11 +3,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         -m rnamotif_amd.mrnamotif -descr X.descr [rnamotif options] db.fastn [more files | packs]
 
-One process per GPU.  Every rank reads the database, takes its share of the
-entries -- entries longer than a share are cut into slices of start positions
-(rma_db_create_ranges) -- and scans it; the candidate records travel to rank 0
-in one variable-length gather over RCCL; rank 0 runs the score program and
-prints, in the reference's order, exactly what `rnamotif` prints.  The
+One process per GPU.  Every rank reads the database with the library's own readers
+(rma_pack_read: what rnamotif reads, -fmt and -N included), takes its share of the
+entries -- entries longer than a share are cut into slices of start positions -- and
+uploads only that (rma_db_create_packed_ranges); the candidate records travel to rank 0
+in one variable-length gather over RCCL; rank 0 runs the score program and prints, in
+the reference's order, exactly what `rnamotif` prints.  The
 reference's own parallel driver hands whole files to MPI workers and collects
 their text (/root/reference/src/mrnamotif.c:733,910-917).
 """
@@ -20,7 +21,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 import rnamotif_amd as R
-from rnamotif_amd.distributed import gather_hits, partition_ranges, sort_hits
+from rnamotif_amd.distributed import all_ok, gather_hits, partition_ranges, sort_hits
 
 _VALUE_OPTS = {"-descr", "-xdescr", "-xdfname", "-N", "-fmt"}
 
@@ -38,25 +39,31 @@ def database_files(argv: Sequence[str]) -> List[str]:
     return files
 
 
-def _records(path: str) -> List[Tuple[bytes, bytes, bytes]]:
-    with open(path, "rb") as f:
-        magic = f.read(8)
-    if magic == b"RMAPACK1":
-        pk = R.Pack(path)
-        return [pk.record(i) for i in range(pk.count)]
-    return R.read_fasta(path)
+def _option(argv: Sequence[str], name: str, default: str = "") -> str:
+    argv = list(argv)
+    return argv[argv.index(name) + 1] if name in argv and argv.index(name) + 1 < len(argv) else default
 
 
-def _scan_shard(descr, seqs, ranges, local_rank: int) -> np.ndarray:
-    """This rank's share on its GPU (rma_db_create_ranges + rma_scan)."""
-    if not seqs:
+def _read_database(argv: Sequence[str], files: Sequence[str]) -> "R.Pack":
+    """The sequence files as rnamotif itself reads them -- -fmt fastn|pir|gb, -N, every quirk of
+    FN_/PIR_/GB_fgetseq (dbutil.c:42,130,226): the library's readers (rma_pack_read), packed in
+    memory.  Every rank reads the files; none keeps text."""
+    n = _option(argv, "-N")
+    return R.Pack.read(list(files), fmt=_option(argv, "-fmt"), maxslen=int(n) if n else 0)
+
+
+def _scan_shard(descr, pack, entries, ranges, local_rank: int) -> np.ndarray:
+    """This rank's share on its GPU: its entries of the packed database, each with its range of
+    start positions, straight into HBM (rma_db_create_packed_ranges + rma_scan)."""
+    if not entries:
         return np.zeros((0, descr.hit_stride), np.int32)
     sc = R.Scanner(descr, device=local_rank)
-    return sc.scan(sc.database(seqs, ranges=ranges))
+    return sc.scan(sc.database_from_pack(pack, entries=entries, ranges=ranges))
 
 
 def _init_process_group(world: int, local_rank: int):
     """One process per GPU over RCCL; returns the device the gather uses."""
+    import datetime
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -66,7 +73,7 @@ def _init_process_group(world: int, local_rank: int):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist.init_process_group(backend="nccl", device_id=dev)
+    dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
     return dev
 
 
@@ -79,24 +86,27 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
     dev = _init_process_group(world, local_rank)
     rank = dist.get_rank() if world > 1 else 0
 
-    if "-fmt" in argv and argv[list(argv).index("-fmt") + 1] != "fastn":
-        raise SystemExit("mrnamotif reads fastn files and packed databases; convert other formats with rnamotif_pack")
-    descr = R.Descriptor(list(argv))
-    files = database_files(argv)
-    if not files:
-        raise SystemExit("mrnamotif: no sequence file")
-    recs: List[Tuple[bytes, bytes, bytes]] = []
-    for f in files:
-        recs.extend(_records(f))
-    if rank == 0 and "-descr" in argv:
-        name = argv[list(argv).index("-descr") + 1]
-        mx = "UNBND" if descr.maxlen == 0x7fffffff else str(descr.maxlen)
-        sys.stderr.write(f"{name}: complete descr length: min/max = {descr.minlen}/{mx}\n")
-
-    mine = partition_ranges([len(r[2]) for r in recs], world)[rank]
-    seqs = [recs[i][2] for i, _, _ in mine]
-    ranges = [(lo, hi) for _, lo, hi in mine]
-    hits = _scan_shard(descr, seqs, ranges, local_rank)
+    # a rank that cannot do its part says so before the gather: nobody is left waiting
+    failure, descr, pack, hits, mine = None, None, None, None, []
+    try:
+        descr = R.Descriptor(list(argv))
+        files = database_files(argv)
+        if not files:
+            raise R.RnamotifError("mrnamotif: no sequence file")
+        pack = _read_database(argv, files)
+        if rank == 0 and "-descr" in argv:
+            mx = "UNBND" if descr.maxlen == 0x7fffffff else str(descr.maxlen)
+            sys.stderr.write(f"{_option(argv, '-descr')}: complete descr length: min/max = {descr.minlen}/{mx}\n")
+        mine = partition_ranges(pack.lengths(), world)[rank]
+        hits = _scan_shard(descr, pack, [i for i, _, _ in mine], [(lo, hi) for _, lo, hi in mine], local_rank)
+    except Exception as e:      # noqa: BLE001 -- reported below, on every rank
+        failure = e
+    if not all_ok(failure is None, dev):
+        if failure is not None:
+            sys.stderr.write(f"mrnamotif (rank {rank}): {failure}\n")
+        if world > 1:
+            dist.destroy_process_group()
+        return 1
     if world > 1:
         hits = gather_hits(hits, [i for i, _, _ in mine], descr.hit_stride, device=dev)
     elif hits.shape[0]:
@@ -105,7 +115,7 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
         hits = sort_hits(hits)
     if rank == 0:
         rp = R.Replay(descr, out_path)
-        rp.batch([r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], hits)
+        rp.pack(pack, hits)
         rp.close()
     if world > 1:
         dist.barrier()

@@ -149,8 +149,8 @@ def cpu_group(world, local_rank):
         dist.init_process_group(backend="gloo")
     return None
 
-def cpu_scan(descr, seqs, ranges, local_rank):
-    h = oracle_scan(descr, seqs)
+def cpu_scan(descr, pack, entries, ranges, local_rank):
+    h = oracle_scan(descr, [pack.record(i)[2] for i in entries])
     keep = np.zeros(h.shape[0], dtype=bool)
     for k, (lo, hi) in enumerate(ranges):
         keep |= (h[:, 0] == k) & (h[:, 2] >= lo) & (h[:, 2] < hi)
@@ -189,3 +189,108 @@ def test_mrnamotif_world2_prints_what_rnamotif_prints(built, workdir, gbrna, tmp
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
     assert p.returncode == 0, p.stdout.decode()[-4000:]
     assert out.read_bytes() == want.stdout
+
+
+MIXED_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import rnamotif_amd as R
+from rnamotif_amd.distributed import partition_by_bases, gather_hits, sort_hits
+from oracle_binding import oracle_scan
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+T = os.path.join(sys.argv[1], "tests", "golden", "test")
+descrs = [R.Descriptor(["-descr", os.path.join(T, n)]) for n in ("sprintf.descr", "mp.ends.descr")]
+rng = np.random.default_rng(23)
+lut = np.frombuffer(b"acgt", dtype=np.uint8)
+# lengths that make the greedy partition interleave the ranks' entries
+seqs = [lut[rng.integers(0, 4, size=int(n))].tobytes() for n in (9000, 30000, 8000, 29000, 7000, 28000, 0, 6000)]
+parts = partition_by_bases([len(s) for s in seqs], world)
+mine = parts[rank]
+assert any(a < b < c for a in parts[0] for b in parts[1] for c in parts[0]), parts    # interleaved
+# one step of a mixed batch: every descriptor over the same shard, two gathers back to back
+got = []
+for d in descrs:
+    local = oracle_scan(d, [seqs[i] for i in mine])
+    got.append(gather_hits(local, mine, d.hit_stride, concat=False))
+if rank == 0:
+    for d, hparts in zip(descrs, got):
+        assert len(hparts) == world
+        want = oracle_scan(d, seqs)
+        merged = sort_hits(np.concatenate(hparts, axis=0))
+        assert want.shape[0] > 0 and merged.shape == want.shape and np.array_equal(merged, want)
+        # every part is in order by itself
+        for h in hparts:
+            assert np.array_equal(sort_hits(h), h)
+else:
+    assert all(g == [] for g in got)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _torchrun(script, args, tmp_path, timeout=600, env=None):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)] + args,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout,
+                          env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})))
+
+
+def test_mixed_batch_interleaved_partitions_world2(built, tmp_path):
+    """concat=False with entries of the ranks interleaved, two descriptors per step (BASELINE
+    config 5's shape): the per-rank parts merge into exactly the single-process hit list."""
+    script = tmp_path / "worker.py"
+    script.write_text(MIXED_WORKER)
+    p = _torchrun(script, [ROOT], tmp_path)
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
+
+
+FAILING_WORKER = MRNAMOTIF_WORKER.replace('''mrnamotif._scan_shard = cpu_scan''', '''def failing_scan(descr, pack, entries, ranges, local_rank):
+    if int(os.environ["RANK"]) == 1:
+        raise RuntimeError("no scanner on this rank")
+    return cpu_scan(descr, pack, entries, ranges, local_rank)
+
+mrnamotif._scan_shard = failing_scan''').replace('''mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], out_path=sys.argv[4])''',
+                                                 '''sys.exit(mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], out_path=sys.argv[4]))''')
+
+
+def test_a_failing_rank_ends_the_job_on_every_rank(built, workdir, gbrna, tmp_path):
+    """One rank cannot scan: no rank is left waiting in the gather; all leave with an error."""
+    import rnamotif_amd as R
+    fa = tmp_path / "db.fastn"
+    fa.write_bytes(b"".join(b">" + s + b" " + d + b"\n" + q + b"\n" for s, d, q in R.read_fasta(gbrna)[:60]))
+    script = tmp_path / "worker.py"
+    script.write_text(FAILING_WORKER)
+    p = _torchrun(script, [ROOT, workdir, str(fa), str(tmp_path / "out.txt")], tmp_path, timeout=300,
+                  env={"EFNDATA": os.path.join(ROOT, "rnamotif_amd", "efndata")})
+    assert p.returncode != 0
+    assert b"no scanner on this rank" in p.stdout
+
+
+def test_mrnamotif_reads_what_rnamotif_reads(built, workdir, gbrna, tmp_path):
+    """The multi-process program reads its database with the library's readers: -N truncation, a
+    '>' in the middle of a line, a PIR file -- rank 0 prints what the single-process program prints."""
+    import rnamotif_amd as R
+    recs = R.read_fasta(gbrna)[:200]
+    fa = tmp_path / "db.fastn"
+    body = b"".join(b">" + s + b" " + d + b"\n" + q + b"\n" for s, d, q in recs[:150])
+    body += recs[150][2][:40] + b">midline entry\n" + recs[151][2] + b"\n"
+    body += b"".join(b">" + s + b" " + d + b"\n" + q + b"\n" for s, d, q in recs[152:])
+    fa.write_bytes(body)
+    env = dict(os.environ, OMP_NUM_THREADS="1", EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    script = tmp_path / "worker.py"
+    for extra, path in ((["-N", "400"], fa),):
+        want = subprocess.run([built["oracle_cli"], "-descr", "sprintf.descr"] + extra + [str(path)], cwd=workdir, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert want.returncode == 0 and want.stdout.count(b"\n>") > 10
+        script.write_text(MRNAMOTIF_WORKER.replace('["-descr", "sprintf.descr", sys.argv[3]]',
+                                                   '["-descr", "sprintf.descr"] + %r + [sys.argv[3]]' % (extra,)))
+        out = tmp_path / "out.txt"
+        p = _torchrun(script, [ROOT, workdir, str(path), str(out)], tmp_path, env={"EFNDATA": env["EFNDATA"]})
+        assert p.returncode == 0, p.stdout.decode()[-4000:]
+        assert out.read_bytes() == want.stdout
