@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the scan path (BASELINE.json).
 
-One step = one pass of the hot path over one synthetic database that is already
-resident in HBM: search kernel over every start position of both strands, efn
-kernel over every candidate, copy back and ordering of the hit records
-(rma_scan of the C ABI).  Workload at N=1: descr/trna.descr (4-stem cloverleaf,
-bits()+efn() score) over the 100 Mbase synthetic FASTA of BASELINE.md
-(100 records x 1 Mbase, iid uniform acgt, numpy default_rng(20240601)).
+One step = one pass of the hot path over one synthetic database that is already resident in
+HBM: search kernel over every start position of both strands, efn kernel over every candidate,
+copy back and ordering of the hit records (rma_scan of the C ABI).  Workload at N=1: descr/
+trna.descr (4-stem cloverleaf, bits()+efn() score) over the 100 Mbase synthetic FASTA of
+BASELINE.md (100 records x 1 Mbase, iid uniform acgt, numpy default_rng(20240601)) -- BASELINE
+config 2.  `value` is that, over exactly --steps steps.
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank scans its own 100 Mbase of the same synthetic stream (records
-[100*rank, 100*rank+100)), i.e. weak scaling; the hit records are gathered to
-rank 0 over RCCL inside the timed region, which is the path's only exchange.
+Next to it, on rank 0 at N=1 with the default workload (none of it inside the timed K steps):
+  sustained        the same step repeated for at least a second
+  h2d_inclusive    SURVEY.md section 8d's step: upload of the packed database (0.375 B/base from host
+                   memory), scan, copy back of the hits -- per step; never `value`
+  north_star_1gbase  the north star's own size: trna.descr over 1 Gbase on one GPU, >= 1 s timed
+  roofline         HBM roofline of the search kernel from HIP events taken here; its two passes
+                   apart (pre-filter alone with RNAMOTIF_DBG=1); HBM traffic and the VALU-issue
+                   secondary roofline from the committed rocprofv3 PMC summary -- only if that
+                   summary was made from the kernel sources this run uses (hash), else null
+  cpu_baseline     the scalar oracle on a bounded sample, one core (and all host cores)
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank scans its own
+--records Mbase of the same synthetic stream (records [records*rank, records*rank+records)), i.e.
+weak scaling; with --total-records R the R records are divided among the ranks (strong scaling:
+BASELINE config 4 is --total-records 1000, config 5 adds --descr qu+tr.descr,mp.ends.descr).  The
+hit records are gathered to rank 0 over RCCL inside the timed region, the path's only exchange.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +40,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_BASE = 0.375      # 2 bit code + 1 bit ambiguity mask, read once for both strands
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+# MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 once two or more
+# waves share the SIMD: 256 CUs x 4 SIMDs x 2.4 GHz / 2
+VALU_PEAK_NOMINAL = 256 * 4 * 2.4e9 / 2 / 1e9
+KERNEL_SOURCES = ("rm_scan_hip.hip", "rm_scan_core.h", "rm_dev_program.h", "rm_dev_program.cpp", "rm_efn_core.h")
+PROFILE = os.path.join(ROOT, "profiles", "r02_trna")     # _pmc_summary.csv, _meta.json (profiles/collect.sh + summarize.py)
+
+
+def kernel_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "rnamotif_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def synthetic_slice(first: int, count: int, length: int):
@@ -42,47 +68,20 @@ def synthetic_slice(first: int, count: int, length: int):
     return out
 
 
-def profiled_traffic(kernel="rma_search_kernel"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (profiles/r01_final7_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE in
-    separate passes over this same default workload, in KiB).  Corrected as
-    MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies 128-byte
-    requests at 64 bytes -> doubled; WRITE_SIZE is exact."""
+def profile_counters(kernel="rma_search_kernel"):
+    """Per-launch means of the committed PMC passes over the default workload -- or None when the
+    summary was made from other kernel sources than the ones this run uses."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final7_pmc_summary.csv")
-    if not os.path.exists(path):
+    meta, summ = PROFILE + "_meta.json", PROFILE + "_pmc_summary.csv"
+    if not (os.path.exists(meta) and os.path.exists(summ)):
         return None
-    kb = {}
-    for r in csv.DictReader(open(path)):
-        if kernel in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            kb[r["counter"]] = float(r["mean_per_dispatch"])
-    if len(kb) != 2:
-        return None
-    return int(2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024)
-
-
-def profiled_issue(kernel_ms, kernel="rma_search_kernel"):
-    """The bound that does apply: instruction issue.  VALU wave-instructions per launch from
-    the committed PMC pass over this workload (SQ_INSTS_VALU) divided by the kernel time
-    measured now, against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per 64-wide VALU instruction;
-    lanes = average active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU)."""
-    import csv
-    path = os.path.join(ROOT, "profiles", "r01_final7_pmc_summary.csv")
-    if not os.path.exists(path):
+    if json.load(open(meta)).get("kernel_hash") != kernel_hash():
         return None
     c = {}
-    for r in csv.DictReader(open(path)):
+    for r in csv.DictReader(open(summ)):
         if kernel in r["kernel"]:
             c[r["counter"]] = float(r["mean_per_dispatch"])
-    if "SQ_INSTS_VALU" not in c:
-        return None
-    peak = 256 * 4 * 2.4e9 / 4 / 1e9
-    ach = c["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / 1e9
-    out = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
-           "frac": round(ach / peak, 4), "salu_per_valu": round(c.get("SQ_INSTS_SALU", 0) / c["SQ_INSTS_VALU"], 3)}
-    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
-        out["active_lanes_of_64"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 1)
-    return out
+    return c or None
 
 
 def cpu_model():
@@ -96,9 +95,8 @@ def cpu_model():
 
 
 def cpu_baseline(descr, seqs, budget_bases):
-    """The scalar CPU oracle (kind 'port': byte-identical to the reference on
-    its golden tests, and within a few percent of its speed here) on a bounded
-    sample of the same workload, one thread."""
+    """The scalar CPU oracle (kind 'port': byte-identical to the reference on its golden tests, and
+    within a few percent of its speed where both ran) on a bounded sample of the same workload, one thread."""
     from oracle_binding import oracle_scan
     sample, got = [], 0
     for s in seqs:
@@ -128,8 +126,8 @@ def _cpu_worker(job):
 
 
 def cpu_baseline_all_cores(descr_path, seqs, bases_per_core):
-    """The reference's own way to use more cores is one process per database file
-    (mrnamotif); the same here: every host core scans its own slice of the database."""
+    """The reference's own way to use more cores is one process per database file (mrnamotif); the
+    same here: every host core scans its own slice of the database."""
     import multiprocessing as mp
     cores = min(len(os.sched_getaffinity(0)), 16, len(seqs))
     jobs = [(descr_path, seqs[k][:bases_per_core]) for k in range(cores)]
@@ -147,67 +145,80 @@ def cpu_baseline_all_cores(descr_path, seqs, bases_per_core):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--records", type=int, default=100, help="1 Mbase records per GPU (default 100 = 100 Mbase)")
+    ap.add_argument("--total-records", type=int, default=0, help="strong scaling: this many records divided among the ranks")
     ap.add_argument("--record-len", type=int, default=1_000_000)
     ap.add_argument("--descr", default=os.path.join(ROOT, "tests", "golden", "descr", "trna.descr"),
                     help="descriptor file; a comma separated list = mixed batch (every descriptor over the same database)")
-    ap.add_argument("--cpu-bases", type=int, default=12_000_000, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-bases", type=int, default=12_000_000, help="sample size of the CPU baseline (0 = skip it and the other extras)")
+    ap.add_argument("--north-star-records", type=int, default=1000, help="records of the 1-GPU north star run (0 = skip)")
     args = ap.parse_args()
 
-    seqs = None
-    cpu_all = None
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_env == 1 and args.cpu_bases > 0 and "," not in args.descr:
+    rank_env = int(os.environ.get("RANK", "0"))
+    default_workload = (args.descr == ap.get_default("descr") and args.records == 100 and
+                        args.record_len == 1_000_000 and args.total_records == 0)
+    extras = world_env == 1 and args.cpu_bases > 0 and "," not in args.descr
+    strong = args.total_records > 0
+    if strong:
+        per = -(-args.total_records // world_env)
+        first_rec = min(args.total_records, rank_env * per)
+        n_rec = max(0, min(args.total_records, first_rec + per) - first_rec)
+    else:
+        first_rec, n_rec = rank_env * args.records, args.records
+
+    seqs_all = None
+    cpu_all = None
+    if extras:
         # host-only work first: worker processes are spawned before this process touches the GPU
-        seqs = synthetic_slice(0, args.records, args.record_len)
-        cpu_all = cpu_baseline_all_cores(args.descr, seqs, min(args.cpu_bases // 2, args.record_len))
+        n_gen = max(n_rec, args.north_star_records if default_workload else 0)
+        seqs_all = synthetic_slice(0, n_gen, args.record_len)
+        cpu_all = cpu_baseline_all_cores(args.descr, seqs_all, min(args.cpu_bases // 2, args.record_len))
 
     import numpy as np
     import torch
     import rnamotif_amd as R
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    world, rank = world_env, rank_env
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(minutes=10))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the scan path has no CPU implementation")
     dev = torch.device("cuda", local_rank)
 
     os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
-    default_workload = (args.descr == ap.get_default("descr") and args.records == 100 and
-                        args.record_len == 1_000_000)
     descr_files = args.descr.split(",")
     descrs = [R.Descriptor(["-descr", f]) for f in descr_files]
     descr = descrs[0]
-    if seqs is None:
-        seqs = synthetic_slice(rank * args.records, args.records, args.record_len)
+    seqs = seqs_all[:n_rec] if seqs_all is not None else synthetic_slice(first_rec, n_rec, args.record_len)
     scs = [R.Scanner(d, device=local_rank) for d in descrs]
     dbs = [s.database(seqs) for s in scs]
     sc, db = scs[0], dbs[0]
 
     from rnamotif_amd.distributed import gather_hits as gather_to_rank0
-    my_index = [rank * args.records + i for i in range(args.records)]   # entry numbers within the whole job
+    my_index = [first_rec + i for i in range(n_rec)]   # entry numbers within the whole job
 
     def gather_hits(h, stride):
         """Variable length gather of hit records to rank 0 over RCCL (rnamotif_amd/distributed.py,
-        the same function the world-size-2 gloo test runs)."""
+        the same function the world-size-2 gloo tests run)."""
         if world == 1:
             return [h]
         # every rank holds a consecutive run of entries: the per-rank arrays in rank order are the
         # ordered hit stream of the whole job, left as they arrive (no concatenation on rank 0)
         return gather_to_rank0(h, my_index, stride, device=dev, concat=False)
 
-    def step():
+    def step(scs_=scs, dbs_=dbs):
         n = 0
-        for d_, sc_, db_ in zip(descrs, scs, dbs):
+        for d_, sc_, db_ in zip(descrs, scs_, dbs_):
             n += sum(part.shape[0] for part in gather_hits(sc_.scan(db_, copy=False), d_.hit_stride))
         return n
 
@@ -230,26 +241,62 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tb = torch.tensor([db.bases], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        job_bases = int(tb.item())
+    else:
+        job_bases = db.bases
 
-    # kernel time of the dominant kernel, HIP events on the scanner's own stream
-    kms = []
-    for _ in range(max(1, min(args.steps, 3))):
-        tot = [0.0, 0.0]
-        for sc_, db_ in zip(scs, dbs):
-            n_cand, s_ms, e_ms = sc_.scan_device(db_)
-            tot[0] += s_ms
-            tot[1] += e_ms
-        kms.append(tuple(tot))
-    search_ms = float(np.mean([k[0] for k in kms]))
-    efn_ms = float(np.mean([k[1] for k in kms]))
+    # kernel time of the dominant kernel, HIP events on the scanner's own stream; then the pre-filter alone
+    def kernel_ms(reps=5):
+        s_tot, e_tot = [], []
+        for _ in range(reps):
+            tot = [0.0, 0.0]
+            for sc_, db_ in zip(scs, dbs):
+                _, s_ms, e_ms = sc_.scan_device(db_)
+                tot[0] += s_ms
+                tot[1] += e_ms
+            s_tot.append(tot[0])
+            e_tot.append(tot[1])
+        return float(np.mean(s_tot)), float(np.mean(e_tot))
 
+    search_ms, efn_ms = kernel_ms()
+    pass_a_ms = None
+    if rank == 0 and world == 1:
+        os.environ["RNAMOTIF_DBG"] = "1"
+        pass_a_ms, _ = kernel_ms(3)
+        os.environ.pop("RNAMOTIF_DBG")
+
+    out = None
     if rank == 0:
         bases_per_gpu = db.bases
-        total_bases = bases_per_gpu * world * len(descrs)   # mixed batch: every descriptor scans every base
+        total_bases = job_bases * len(descrs)          # mixed batch: every descriptor scans every base
         ms_per_step = dt / args.steps * 1e3
         value = total_bases / (dt / args.steps) / 1e6
-        achieved = ALGO_BYTES_PER_BASE * bases_per_gpu * len(descrs) / (search_ms * 1e-3) / 1e9
+        algo_bytes = ALGO_BYTES_PER_BASE * bases_per_gpu * len(descrs)
+        achieved = algo_bytes / (search_ms * 1e-3) / 1e9
         names = "+".join(os.path.basename(f) for f in descr_files)
+        counters = profile_counters() if default_workload and world == 1 else None
+        traffic = None
+        secondary = None
+        if counters and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            # KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950 -> doubled (MI355X_MICROARCH.md, HBM)
+            traffic = int(2 * counters["FETCH_SIZE"] * 1024 + counters["WRITE_SIZE"] * 1024)
+        if counters and "SQ_INSTS_VALU" in counters:
+            ach = counters["SQ_INSTS_VALU"] / (search_ms * 1e-3) / 1e9
+            measured_peak = None
+            vp = os.path.join(ROOT, "profiles", "r02_valu_peak.json")
+            if os.path.exists(vp):
+                measured_peak = json.load(open(vp)).get("waves_per_simd_4")
+            secondary = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(VALU_PEAK_NOMINAL, 1),
+                         "unit": "G wave64-instr/s", "frac": round(ach / VALU_PEAK_NOMINAL, 4),
+                         "peak_measured": measured_peak,
+                         "frac_of_measured": round(ach / measured_peak, 4) if measured_peak else None,
+                         "formula": "SQ_INSTS_VALU per launch (profiles/r02_trna_pmc_summary.csv) / kernel_ms of this run; "
+                                    "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; peak_measured = profiles/valu_peak.hip at 4 waves per SIMD",
+                         "salu_per_valu": round(counters.get("SQ_INSTS_SALU", 0) / counters["SQ_INSTS_VALU"], 3)}
+            if "SQ_THREAD_CYCLES_VALU" in counters and "SQ_ACTIVE_INST_VALU" in counters:
+                secondary["active_lanes_of_64"] = round(counters["SQ_THREAD_CYCLES_VALU"] / counters["SQ_ACTIVE_INST_VALU"], 1)
         out = {
             "metric": "Mbases scanned/sec (whole node) + hits/sec, " + names,
             "value": round(value, 3),
@@ -260,14 +307,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
                 "workload": f"{names} ({'mixed batch, ' if len(descrs) > 1 else ''}{'+'.join(str(d.n_elems) for d in descrs)} elements) over "
-                            f"{args.records} x {args.record_len} base synthetic records per GPU "
-                            f"(iid uniform acgt, numpy default_rng(20240601)), both strands",
+                            + (f"{args.total_records} x {args.record_len} base synthetic records divided among the ranks" if strong else
+                               f"{args.records} x {args.record_len} base synthetic records per GPU")
+                            + " (iid uniform acgt, numpy default_rng(20240601)), both strands; database resident in HBM",
                 "bases_per_gpu": bases_per_gpu,
                 "total_bases": total_bases,
                 "candidates": total_hits,
@@ -280,24 +328,84 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 8),
-                "traffic": profiled_traffic() if default_workload and world == 1 else None,
-                "traffic_note": "bytes per launch from the committed PMC passes of this workload "
-                                "(profiles/r01_final7_pmc_summary.csv), 2 x FETCH_SIZE + WRITE_SIZE",
-                "algorithmic_bytes": int(ALGO_BYTES_PER_BASE * bases_per_gpu * len(descrs)),
-                "kernel_ms": round(search_ms, 3),
-                "efn_kernel_ms": round(efn_ms, 3),
+                "traffic": traffic,
+                "traffic_note": "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes over this workload "
+                                "(profiles/r02_trna_pmc_summary.csv); null when that summary was made from other kernel sources",
+                "algorithmic_bytes": int(algo_bytes),
                 "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE,
-                "secondary": profiled_issue(search_ms) if default_workload and world == 1 else None,
-                "note": "the search is integer/LDS issue bound, not HBM bound (SURVEY.md 8d); "
+                "kernel_ms": round(search_ms, 3),
+                "pass_a_ms": round(pass_a_ms, 3) if pass_a_ms is not None else None,
+                "pass_b_ms": round(search_ms - pass_a_ms, 3) if pass_a_ms is not None else None,
+                "efn_kernel_ms": round(efn_ms, 3),
+                "kernel_hash": kernel_hash(),
+                "secondary": secondary,
+                "note": "the search is integer/LDS work with dependent accesses, not HBM bound (SURVEY.md 8d); pass A = "
+                        "pre-filter (decode, bit rows, first-pairs test, queue), pass B = the search proper; "
                         "kernel-only rate = %.1f Mbases/s" % (bases_per_gpu * len(descrs) / (search_ms * 1e-3) / 1e6),
             },
         }
-        if world == 1 and args.cpu_bases > 0:
-            out["cpu_baseline"] = cpu_baseline(descr, seqs, args.cpu_bases)
-            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-            out["cpu_baseline_all_cores"] = cpu_all
-        else:
-            out["cpu_baseline"] = None
+
+    if rank == 0 and extras:
+        # ---- the same step for at least a second
+        n_sus, t0 = 0, time.perf_counter()
+        while True:
+            step()
+            n_sus += 1
+            if time.perf_counter() - t0 >= 1.2:
+                break
+        torch.cuda.synchronize()
+        ds = time.perf_counter() - t0
+        out["sustained"] = {"steps": n_sus, "seconds": round(ds, 3), "value": round(db.bases * n_sus / ds / 1e6, 3), "unit": "Mbases/s"}
+
+        # ---- SURVEY 8d's step: upload of the packed database + scan + copy back of the hits
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            pkpath = os.path.join(tmp, "syn.rmpk")
+            R.Pack.write(pkpath, [(b"syn%04d" % i, b"", s) for i, s in enumerate(seqs)])
+            pack = R.Pack(pkpath)
+            for _ in range(2):
+                d2 = sc.database_from_pack(pack)
+                sc.scan(d2, copy=False)
+                d2.close()
+            n_h2d, t0 = 0, time.perf_counter()
+            while n_h2d < 10 or time.perf_counter() - t0 < 0.5:
+                d2 = sc.database_from_pack(pack)
+                sc.scan(d2, copy=False)
+                d2.close()
+                n_h2d += 1
+            torch.cuda.synchronize()
+            dh = time.perf_counter() - t0
+            pack.close()
+        out["h2d_inclusive"] = {"value": round(db.bases * n_h2d / dh / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dh / n_h2d * 1e3, 3),
+                                "steps": n_h2d,
+                                "what": "per step: device allocation, upload of the packed database from pageable host memory "
+                                        "(0.375 B/base), search + efn kernels, copy back and ordering of the hits, free; not `value`"}
+
+        # ---- the north star's own size on one GPU
+        if default_workload and args.north_star_records > n_rec and seqs_all is not None and len(seqs_all) >= args.north_star_records:
+            big = seqs_all[: args.north_star_records]
+            db.close()
+            bdb = sc.database(big)
+            for _ in range(2):
+                sc.scan(bdb, copy=False)
+            n_big, hits_big, t0 = 0, 0, time.perf_counter()
+            while n_big < 5 or time.perf_counter() - t0 < 1.0:
+                hits_big = sc.scan(bdb, copy=False).shape[0]
+                n_big += 1
+            torch.cuda.synchronize()
+            dbg = time.perf_counter() - t0
+            _, big_ms, big_efn = sc.scan_device(bdb)
+            out["north_star_1gbase"] = {"value": round(bdb.bases * n_big / dbg / 1e6, 3), "unit": "Mbases/s", "bases": bdb.bases,
+                                        "steps": n_big, "seconds": round(dbg, 3), "ms_per_step": round(dbg / n_big * 1e3, 3),
+                                        "candidates": hits_big, "kernel_ms": round(big_ms, 3), "efn_kernel_ms": round(big_efn, 3),
+                                        "what": "descr/trna.descr over 1000 x 1 Mbase synthetic records on one GPU, database resident in HBM"}
+            bdb.close()
+        out["cpu_baseline"] = cpu_baseline(descr, seqs, args.cpu_bases)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        out["cpu_baseline_all_cores"] = cpu_all
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -12,6 +12,13 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+# what the profiled binary was built from: bench.py quotes the counters only for the same sources
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import json
+from bench import kernel_hash
+with open(dst + "_meta.json", "w") as out:
+    json.dump({"kernel_hash": kernel_hash(), "source": src}, out)
+    out.write("\n")
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     shutil.copy(f, dst + "_kernel_stats.csv")
 with open(dst + "_pmc_summary.csv", "w") as out:
