@@ -332,6 +332,21 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		if( show_progress > 0 && ecnt % show_progress == 0 )
 			fprintf( stderr, "%s: %7d: %s\n", d.args.argv0.c_str(), ecnt, sid );
 	};
+	// the EOF of file f: DB_fnext (dbutil.c:12-40) opens the next file before the main loop counts
+	// the EOF as an entry (rnamot.c:160-168); a file that cannot be read ends the run uncounted
+	bool	stop = false;
+	auto next_file = [&]( size_t f ){
+		if( use_stdin || f + 1 >= nfiles )
+			return;
+		FILE	*t = fopen( d.args.dbfnames[ f + 1 ].c_str(), "r" );
+		if( t == nullptr ){
+			fprintf( stderr, "DB_fnext: can't read seq file '%s'.\n", d.args.dbfnames[ f + 1 ].c_str() );
+			stop = true;
+			return;
+		}
+		fclose( t );
+		tick( "" );
+	};
 	auto submit = [&]( std::unique_ptr<PackFile> own, const PackFile *pk, int first, int count ){
 		int64_t	bases = 0;
 		for( int i = 0; i < count; i++ ){
@@ -396,13 +411,12 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 			first += count;
 		}
 	};
-	for( size_t f = 0; f < nfiles; f++ ){
+	for( size_t f = 0; f < nfiles && !stop; f++ ){
 		FILE	*fp = stdin;
 		if( !use_stdin && PackFile::is_pack( d.args.dbfnames[ f ] ) ){
 			flush();
 			scan_pack( d.args.dbfnames[ f ] );
-			if( f + 1 < nfiles )
-				ecnt++;		// the EOF that switches files is counted, rnamot.c:160-168
+			next_file( f );
 			continue;
 		}
 		long	resume_at = 0;
@@ -422,10 +436,7 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 					submit( std::move( pk ), p, 0, p->count() );
 				}
 				if( fs.stopped_at() < 0 ){
-					// rnamot.c:160-176: the entry counter also ticks for the EOF that switches to
-					// the next file (with an empty name), not for the one that ends the run
-					if( f + 1 < nfiles )
-						tick( "" );
+					next_file( f );
 					continue;
 				}
 				resume_at = long( fs.stopped_at() );	// an entry the reader has something to say about
@@ -434,7 +445,7 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		if( !use_stdin ){
 			fp = fopen( d.args.dbfnames[ f ].c_str(), "r" );
 			if( fp == nullptr ){
-				// DB_fnext, dbutil.c:12-40: report and stop
+				// DB_fnext, dbutil.c:12-40: report and stop (the first file; later ones are tried at the EOF before them)
 				fprintf( stderr, "DB_fnext: can't read seq file '%s'.\n", d.args.dbfnames[ f ].c_str() );
 				break;
 			}
@@ -444,12 +455,11 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		FastaReader	rd( fp, d.args.maxslen, seq_format_of( d.args.dbfmt ) );
 		SeqRecord	rec;
 		for( ; ; ){
-			const bool	got = rd.next( rec );
-			if( !got && ( use_stdin || f + 1 >= nfiles ) )
+			if( !rd.next( rec ) ){
+				next_file( f );
 				break;
-			tick( got ? rec.sid.c_str() : "" );
-			if( !got )
-				break;
+			}
+			tick( rec.sid.c_str() );
 			st.n_seqs++;
 			st.n_bases += int64_t( rec.seq.size() );
 			in_batch += int64_t( rec.seq.size() );

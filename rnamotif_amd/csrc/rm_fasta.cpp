@@ -114,8 +114,10 @@ bool FastaReader::next_pir( SeqRecord &rec )	// PIR_fgetseq, dbutil.c:130-224
 	const unsigned	s_sdef = 20000;
 	unsigned	cnt = 1;
 	c = get();
-	if( c != EOF )		// (a newline too: an empty title line swallows the line after it)
-		rec.sdef.push_back( char( c ) );
+	// (a newline too: an empty title line swallows the line after it; and the EOF of a file that
+	// ends with the name line, stored as the character it converts to -- pinned against the
+	// reference's reader, tests/test_reader_pins.py)
+	rec.sdef.push_back( char( c ) );
 	while( ( c = get() ) != 0 ){
 		if( c == '\n' || c == EOF )
 			break;

@@ -41,13 +41,21 @@ def test_strict_md5(built, workdir, name):
     assert hashlib.md5(out).hexdigest() == pins.STRICT[name][1]
 
 
+# all 12 slack and 12 strict targets of the reference's test/Makefile (pk1 with -sh: 25 s)
+CHK = [(n, False) for n in ("nanlin", "pk1", "pk_j1+2", "qu+tr", "score.1", "score.2", "trna", "mp.ends", "efn",
+                            "sprintf", "bulge", "getbest")]
+CHK += [(n, True) for n, _ in CHK]
+
+
 @pytest.mark.skipif(not os.path.exists(REF_RMFMT), reason="oracle/_ref/rmfmt not built (no /root/reference)")
-@pytest.mark.parametrize("name", ["nanlin", "pk_j1+2", "qu+tr", "score.1", "score.2", "trna", "mp.ends", "efn",
-                                  "sprintf", "bulge"])
-def test_chk_files_through_reference_rmfmt(built, workdir, name):
-    """test/Makefile:34-37: rnamotif ... | rmfmt -l  must equal NAME.chk."""
-    out, _ = _run(built, workdir, ["-descr", name + ".descr"])
+@pytest.mark.parametrize("name,strict", CHK, ids=[n + (".strict" if s else "") for n, s in CHK])
+def test_chk_files_through_reference_rmfmt(built, workdir, name, strict):
+    """test/Makefile:34-37,139-245: rnamotif [-sh -context -Dctx_maxlen=5] -descr NAME[.strict].descr
+    gbrna.111.0.fastn | rmfmt -l  must equal the reference's NAME[.strict].chk -- the vectors the
+    reference itself holds for this path, through the reference's own rmfmt."""
+    stem = name + (".strict" if strict else "")
+    out, _ = _run(built, workdir, (pins.STRICT_ARGS if strict else []) + ["-descr", stem + ".descr"])
     p = subprocess.run([REF_RMFMT, "-l"], input=out, cwd=workdir, stdout=subprocess.PIPE, timeout=300,
                        env=dict(os.environ, LC_ALL="C"))
-    want = open(os.path.join(ROOT, "tests", "golden", "test", name + ".chk"), "rb").read()
+    want = open(os.path.join(ROOT, "tests", "golden", "test", stem + ".chk"), "rb").read()
     assert p.stdout == want
