@@ -301,7 +301,7 @@ template< class X > RMD_FN int rme2_efn2( const X &x )	// RM_efn2 :1103
 // Energy of efn2 site k for the hit record w (do_sc_efnx, score.c:1672-1679, before the 0.01).
 template< class Seq >
 RMD_FN int rme2_site_energy( const rmd_program_t *P, const rma_efn2data_t *E, const Seq *sq, const int32_t *w, int k,
-	int16_t *bpbuf = nullptr, uint8_t *bcbuf = nullptr )
+	int16_t *bpbuf = nullptr, uint8_t *bcbuf = nullptr, int cache = 0 )
 {
 	rme_cand_t<Seq>	c;
 	c.P = P;
@@ -309,7 +309,7 @@ RMD_FN int rme2_site_energy( const rmd_program_t *P, const rma_efn2data_t *E, co
 	c.sq = sq;
 	if( !c.setup( P->efn_sites[ k ] ) )
 		return RME_INF;
-	if( bpbuf != nullptr && c.len <= RME_CACHE )
+	if( bpbuf != nullptr && c.len <= cache )
 		c.fill_cache( bpbuf, bcbuf );
 	rme2_ctx_t< rme_cand_t<Seq> >	x;
 	x.E = E;

@@ -502,10 +502,11 @@ struct rme_cand_t {
 
 // Energy of efn site k for the hit record w; what do_sc_efnx() returns before
 // the 0.01 scaling (score.c:1672-1679).
-#define RME_CACHE	192	// longest call whose base and pair arrays the kernel keeps in LDS
+// (bpbuf/bcbuf: room for the base codes and partners of a call of up to cache bases; longer calls
+// compute them on demand from the hit record)
 template< class Seq >
 RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const Seq *sq, const int32_t *w, int k,
-	int16_t *bpbuf = nullptr, uint8_t *bcbuf = nullptr )
+	int16_t *bpbuf = nullptr, uint8_t *bcbuf = nullptr, int cache = 0 )
 {
 	rme_cand_t<Seq>	c;
 	c.P = P;
@@ -513,7 +514,7 @@ RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const
 	c.sq = sq;
 	if( !c.setup( P->efn_sites[ k ] ) )
 		return RME_INF;
-	if( bpbuf != nullptr && c.len <= RME_CACHE )
+	if( bpbuf != nullptr && c.len <= cache )
 		c.fill_cache( bpbuf, bcbuf );
 	rme_ctx_t< rme_cand_t<Seq> >	x;
 	x.T = T;

@@ -979,6 +979,12 @@ struct DevSeq {
 };
 
 #define RME_N16_PAD	( ( RME_N16 + 7 ) / 8 * 8 )
+// One workgroup of 256 lanes per CU: efn's tables (60.7 KB as int16) are staged once per
+// workgroup, every lane keeps the base codes and partners of its call in LDS while it is no
+// longer than EFN_CACHE bases (a cloverleaf is under 96) -- 136 KB in all -- and the candidates
+// are taken in a grid-stride loop, so the staging is paid once per CU and four waves share it.
+#define EFN_BLOCK	256
+#define EFN_CACHE	96
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK )
 rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
@@ -991,22 +997,21 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 			reinterpret_cast<uint4 *>( t16 )[ i ] = reinterpret_cast<const uint4 *>( g16 )[ i ];
 	__syncthreads();
 	// per lane: base codes and partners of the call, when it is short enough
-	__shared__ int16_t	s_bp[ BLOCK ][ RME_CACHE + 1 ];
-	__shared__ uint8_t	s_bc[ BLOCK ][ RME_CACHE + 4 ];
-	long long	h = ( long long )blockIdx.x * BLOCK + threadIdx.x;
-	if( h >= n_hits )
-		return;
+	__shared__ int16_t	s_bp[ BLOCK ][ EFN_CACHE + 1 ];
+	__shared__ uint8_t	s_bc[ BLOCK ][ EFN_CACHE + 4 ];
 	rme_tables_t	T{ t16, tlkey, loginc };
 	int16_t	*bpbuf = s_bp[ threadIdx.x ];
 	uint8_t	*bcbuf = s_bc[ threadIdx.x ];
-	int32_t	*w = hits + h * gP->hit_stride;
-	DevSeq	sq{ db, db.base_off[ w[ 0 ] ], db.slen[ w[ 0 ] ], w[ 1 ] };
 	const int	efn_off = RMA_HIT_HDR + 4 * gP->n_elems + 4;
-	for( int k = 0; k < gP->n_efn; k++ ){
-		if( gP->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
-			w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy( gP, e2, &sq, w, k, bpbuf, bcbuf ) : RME2_INF;
-		else if( g16 != nullptr )
-			w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k, bpbuf, bcbuf );
+	for( long long h = ( long long )blockIdx.x * BLOCK + threadIdx.x; h < n_hits; h += ( long long )gridDim.x * BLOCK ){
+		int32_t	*w = hits + h * gP->hit_stride;
+		DevSeq	sq{ db, db.base_off[ w[ 0 ] ], db.slen[ w[ 0 ] ], w[ 1 ] };
+		for( int k = 0; k < gP->n_efn; k++ ){
+			if( gP->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
+				w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy( gP, e2, &sq, w, k, bpbuf, bcbuf, EFN_CACHE ) : RME2_INF;
+			else if( g16 != nullptr )
+				w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k, bpbuf, bcbuf, EFN_CACHE );
+		}
 	}
 }
 
@@ -1613,8 +1618,9 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		HIPCHK( hipEventElapsedTime( search_ms, sc->ev[ 0 ], sc->ev[ 1 ] ) );
 	*n_hits = int64_t( count );
 	if( ( sc->have_efn || sc->d_efn2 != nullptr ) && dp.n_efn > 0 && count > 0 ){
-		constexpr int	EB = 64;
-		int64_t	blocks = ( int64_t( count ) + EB - 1 ) / EB;
+		constexpr int	EB = EFN_BLOCK;
+		// one workgroup per CU at most (its LDS), each striding over the candidates
+		const int64_t	blocks = std::min<int64_t>( ( int64_t( count ) + EB - 1 ) / EB, sc->grid_blocks / 8 );
 		HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
 		hipLaunchKernelGGL( rma_efn_kernel<EB>, dim3( unsigned( blocks ) ), dim3( EB ), 0, sc->stream,
 			sc->d_prog, v, sc->d_hits, ( long long )count, sc->have_efn ? sc->d_t16 : nullptr, sc->d_tlkey, sc->d_loginc,

@@ -16,13 +16,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_RMFMT = os.path.join(ROOT, "oracle", "_ref", "rmfmt")
 
 
+_RUNS = {}      # (the md5 pins and the .chk comparisons look at the same 24 runs)
+
+
 def _run(built, workdir, args):
+    key = tuple(args)
+    if key in _RUNS:
+        return _RUNS[key]
     env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"),
                RMO_EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
     p = subprocess.run([built["oracle_cli"]] + args + ["gbrna.111.0.fastn"], cwd=workdir, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
     assert p.returncode == 0, p.stderr.decode()
-    return p.stdout, p.stderr
+    _RUNS[key] = (p.stdout, p.stderr)
+    return _RUNS[key]
 
 
 # pk1 (18 s) and getbest (7 s) dominate; everything together stays under a minute

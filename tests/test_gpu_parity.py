@@ -435,6 +435,32 @@ def test_n_rich_synthetic_equals_oracle(built, workdir):
         assert got.shape == want.shape and np.array_equal(got, want), name
 
 
+def test_hit_dense_energy_sites(built, workdir, gbrna, tmp_path):
+    """Many candidates per base: efn.descr (a tetraloop hairpin scored with efn()) and a hairpin
+    without sequence constraint scored with efn() and efn2(), over the reference's test database
+    five times (11.3 Mbase of rRNA and tRNA genes) -- every record, energies included, equal to the
+    oracle's; the time of the energy kernel is printed (one workgroup of 256 lanes per CU, tables
+    staged once per workgroup, candidates in a grid-stride loop)."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    seqs = [r[2] for r in R.read_fasta(gbrna)] * 5
+    dense = tmp_path / "dense.descr"
+    dense.write_text("parms\n\twc += gu;\ndescr\n\th5( minlen=5, maxlen=9, tag='a' )\n\t\tss( minlen=3, maxlen=8 )\n\th3( tag='a' )\n"
+                     "score\n\t{ SCORE = efn( h5['a'], h3['a'] ) + efn2( h5['a'], h3['a'] ); }\n")
+    for path in (os.path.join(workdir, "efn.descr"), str(dense)):
+        d = R.Descriptor(["-descr", path])
+        sc = R.Scanner(d)
+        db = sc.database(seqs)
+        got = sc.scan(db)
+        want = oracle_scan(d, seqs)
+        assert got.shape == want.shape and np.array_equal(got, want), path
+        n, s_ms, e_ms = sc.scan_device(db)
+        n, s_ms, e_ms = sc.scan_device(db)
+        print("\n%s: %d candidates over %d bases (%.0f per Mbase), search kernel %.2f ms, energy kernel %.2f ms = %.2f us per candidate"
+              % (os.path.basename(path), n, db.bases, n / (db.bases / 1e6), s_ms, e_ms, 1e3 * e_ms / max(n, 1)))
+        assert n == want.shape[0] and n > 2000
+
+
 def test_one_long_entry(built, workdir):
     """A single 12 Mbase entry (coordinates far beyond 16 bits, thousands of tiles): the
     whole-entry scan equals the union of three start-position slices of it, and every record
