@@ -467,8 +467,16 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			d->offset[ k ] = int16_t( p->sites[ s ].pos[ k ].offset );
 		}
 	}
-	for( int k = 0; k < p->n_efn_sites; k++ )
+	for( int k = 0; k < p->n_efn_sites; k++ ){
 		out->efn_sites[ k ] = p->efn_sites[ k ];
+		// the energy functions walk loops with fixed stacks (rm_efn_core.h RME_STK, rm_efn2_core.h
+		// RME2_MAXHELIX): a call over more helices than they can hold is refused here, not answered wrongly
+		int	lo = p->efn_sites[ k ].idx, hi = p->efn_sites[ k ].idx2, helices = 0;
+		for( int d = std::max( 0, std::min( lo, hi ) ); d <= std::max( lo, hi ) && d < p->n_elems; d++ )
+			helices += p->elems[ d ].type == RMA_T_H5;
+		if( helices > 15 )
+			FAIL( "efn()/efn2() call over %d helices; the device scanner takes at most 15", helices );
+	}
 	// Best literal (optimize_query, compile.c:3315-3392; mm_classccnt, mm_regexp.c:232):
 	// the fixed-length seq= with the most "effective characters" whose offset from the
 	// start of the motif is bounded.  Necessary condition only, so output neutral.

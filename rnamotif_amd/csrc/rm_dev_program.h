@@ -12,7 +12,7 @@
 #include "rnamotif_amd_program.h"
 
 #ifndef RMD_MAX_ELEMS
-#define RMD_MAX_ELEMS	32	// elements (and search levels) per descriptor on the device
+#define RMD_MAX_ELEMS	100	// elements (and search levels) per descriptor: the reference's own limit, compile.c:49
 #endif
 #define RMD_LEAN_LEVELS	16	// most search levels the lean path takes
 #define RMD_MAX_HLEN	63	// longest helix strand: candidate sets are 64-bit masks

@@ -173,6 +173,9 @@ bool PackFile::load( const std::string &path, std::string &err )
 				base_off[ i ] / 32 + nw1 <= int64_t( amask.size() ) &&
 				base_off[ i ] / 16 + 2 * nw1 <= int64_t( codes.size() ) &&
 				exc_off[ i ] >= 0 && exc_off[ i ] <= int64_t( exc.size() );
+			// entries follow each other without overlap (a slice of the arrays is uploaded as it is)
+			ok = ok && ( i == 0 || ( base_off[ i ] >= base_off[ i - 1 ] + ( ( int64_t( slen[ i - 1 ] ) + 31 ) / 32 ) * 32 &&
+				exc_off[ i ] >= exc_off[ i - 1 ] ) );
 			total_bases += slen[ i ];
 		}
 		size_t	nul = 0;

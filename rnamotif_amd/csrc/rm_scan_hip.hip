@@ -1047,6 +1047,7 @@ struct rma_scanner {
 
 struct rma_db {
 	rma_scanner	*sc;
+	int	device = 0;		// (kept here: a database may outlive its scanner)
 	uint32_t	*d_codes = nullptr, *d_amask = nullptr;
 	int64_t	*d_base_off = nullptr, *d_tile_start = nullptr;
 	int32_t	*d_tile_seq = nullptr;
@@ -1056,6 +1057,9 @@ struct rma_db {
 	int64_t	n_tiles = 0, total_bases = 0;
 	int	strands = 2;
 };
+
+extern "C" void rma_db_destroy( rma_db_t *db );
+extern "C" void rma_scanner_destroy( rma_scanner_t *sc );
 
 static void build_tables16( const rma_efndata_t *ed, std::vector<int16_t> &t16, std::vector<int32_t> &tlkey )
 {
@@ -1120,6 +1124,14 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	rma_scanner_t **out, char *err, size_t errlen )
 {
 	*out = nullptr;
+	rma_scanner	*sc = new rma_scanner;
+	// every early return below releases the scanner and what it holds by then
+	struct ScGuard { rma_scanner *p; ~ScGuard(){ if( p ) rma_scanner_destroy( p ); } }	guard{ sc };
+	sc->prog = *prog;
+	// (host work first: a descriptor outside the device limits is refused with its reason whether
+	// or not a device is there to refuse it for)
+	if( rmd_build( prog, &sc->dprog, err, errlen ) )
+		return 1;
 	int	ndev = 0;
 	if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 ){
 		snprintf( err, errlen, "no HIP device available: the rnamotif scan path runs on the GPU only" );
@@ -1129,12 +1141,6 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		snprintf( err, errlen, "device %d out of range (0..%d)", device, ndev - 1 );
 		return 1;
 	}
-	rma_scanner	*sc = new rma_scanner;
-	sc->prog = *prog;
-	if( rmd_build( prog, &sc->dprog, err, errlen ) ){
-		delete sc;
-		return 1;
-	}
 	if( const char *sb = getenv( "RNAMOTIF_BUDGET" ) )		// launch-shape switch: iterations per step
 		sc->dprog.step_budget = std::max( 4, atoi( sb ) );
 	for( int k = 0; k < prog->n_efn_sites; k++ ){
@@ -1142,7 +1148,6 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 			sc->need_efn2 = true;	// tables come with rma_scanner_set_efn2data(), checked at the first scan
 		else if( efn == nullptr ){
 			snprintf( err, errlen, "the program has efn() call sites but no energy tables were given" );
-			delete sc;
 			return 1;
 		}
 	}
@@ -1261,7 +1266,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	}
 	if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )
 		if( atoi( qq ) >= 64 && atoi( qq ) <= 16384 )
-			sc->qcap = atoi( qq );
+			sc->qcap = ( atoi( qq ) + 3 ) & ~3;	// (what follows the queue in LDS is read 8 bytes at a time)
 	const char	*tt = getenv( "RNAMOTIF_TILE" );
 	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 16384 )
 		sc->tile_t = atoi( tt );
@@ -1270,6 +1275,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	// size (count-then-emit, rma_scan_device)
 	sc->hit_cap = 1 << 17;
 	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
+	guard.p = nullptr;
 	*out = sc;
 	return 0;
 }
@@ -1287,6 +1293,10 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 {
 	if( sc == nullptr )
 		return;
+	if( sc->d_prog == nullptr && sc->stream == nullptr ){	// (refused before anything was set up on a device)
+		delete sc;
+		return;
+	}
 	( void )hipSetDevice( sc->device );
 	( void )hipFree( sc->d_prog );
 	( void )hipFree( sc->d_efn2 );
@@ -1320,7 +1330,10 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 			}
 	rma_db	*db = new rma_db;
 	db->sc = sc;
+	db->device = sc->device;
 	db->n_seq = n;
+	// every early return below frees what has been allocated so far
+	struct DbGuard { rma_db *p; ~DbGuard(){ if( p ) rma_db_destroy( p ); } }	guard{ db };
 	db->total_bases = 0;
 	db->strands = sc->prog.chk_both_strs ? 2 : 1;
 	std::vector<int64_t>	tile_start( size_t( n ) + 1, 0 );
@@ -1398,6 +1411,7 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 		HIPCHK( hipMemcpy( db->d_pos_lo, pos_lo, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
 		HIPCHK( hipMemcpy( db->d_pos_hi, pos_hi, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
 	}
+	guard.p = nullptr;
 	*out = db;
 	return 0;
 }
@@ -1477,7 +1491,7 @@ extern "C" void rma_db_destroy( rma_db_t *db )
 {
 	if( db == nullptr )
 		return;
-	( void )hipSetDevice( db->sc->device );
+	( void )hipSetDevice( db->device );
 	( void )hipFree( db->d_codes );
 	( void )hipFree( db->d_amask );
 	( void )hipFree( db->d_base_off );

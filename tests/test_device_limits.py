@@ -1,0 +1,62 @@
+"""What the device scanner refuses, and with which words (INTEGRATION.md lists the same): the
+reference takes these descriptors; this build has no CPU search path to fall back to, so each is
+refused before any scan -- at descriptor compilation or at rma_scanner_create(), whose host part
+(rmd_build) runs before a device is asked for, so the refusals are testable here.  What is NOT
+refused any more: up to 100 elements, the reference's own limit (compile.c:49)."""
+import os
+
+import pytest
+
+import rnamotif_amd as R
+
+CASES = [
+    ("helix of up to 80 base pairs",
+     "descr\n\th5(minlen=4,maxlen=80)\n\t\tss(minlen=3,maxlen=8)\n\th3\n",
+     "scanner", "helix element 1 allows 80 base pairs; the device scanner takes at most 63"),
+    ("seq= that expands to more than 63 positions",
+     'descr\n\tss(minlen=70,maxlen=90,seq="^' + "acgt" * 17 + '")\n',
+     "compile", "cannot run on the device scanner: seq= pattern to"),
+    ("back-reference in seq=",
+     'descr\n\tss(minlen=4,maxlen=10,seq="\\(ac\\)g\\1")\n',
+     "compile", "cannot run on the device scanner"),
+    ("iupac = 0 with a letter that is not acgt in seq=",
+     'parms\n\tiupac = 0;\ndescr\n\tss(minlen=4,maxlen=10,seq="nnac")\n',
+     "compile", "cannot run on the device scanner: literal 'n' is not one of acgt."),
+    ("efn() over more than 15 helices",
+     "descr\n" + "".join("\th5(tag='h%d',minlen=2,maxlen=3)\n\t\tss(len=3)\n\th3(tag='h%d')\n\tss(len=1)\n" % (i, i) for i in range(17)) +
+     "score\n\t{ SCORE = efn( h5['h0'], h3['h16'] ); }\n",
+     "scanner", "efn()/efn2() call over 17 helices; the device scanner takes at most 15"),
+    ("more than 100 elements (the reference's own limit)",
+     "descr\n" + "".join("\tss(len=1)\n" for _ in range(101)),
+     "compile", "descr array size(100) exceeded."),
+]
+
+
+@pytest.mark.parametrize("what,text,where,message", CASES, ids=[c[0] for c in CASES])
+def test_refusal_and_its_words(built, tmp_path, what, text, where, message):
+    path = tmp_path / "x.descr"
+    path.write_text(text)
+    os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
+    if where == "compile":
+        with pytest.raises(R.RnamotifError) as e:
+            R.Descriptor(["-descr", str(path)])
+    else:
+        d = R.Descriptor(["-descr", str(path)])
+        with pytest.raises(R.RnamotifError) as e:
+            R.Scanner(d)
+    assert message in str(e.value), str(e.value)
+
+
+def test_a_hundred_elements_are_taken(built, tmp_path):
+    """48 and 100 elements pass the host part of rma_scanner_create(); without a GPU the only
+    objection left is the missing device."""
+    for text in ("descr\n" + "".join("\th5(minlen=2,maxlen=3)\n\t\tss(len=3)\n\th3\n\tss(len=1)\n" for _ in range(12)),
+                 "descr\n" + "".join("\tss(len=1)\n" for _ in range(100))):
+        path = tmp_path / "y.descr"
+        path.write_text(text)
+        d = R.Descriptor(["-descr", str(path)])
+        if R.lib().rma_device_count() == 0:
+            with pytest.raises(R.RnamotifError, match="GPU only"):
+                R.Scanner(d)
+        else:
+            R.Scanner(d).close()

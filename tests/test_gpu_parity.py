@@ -435,6 +435,28 @@ def test_n_rich_synthetic_equals_oracle(built, workdir):
         assert got.shape == want.shape and np.array_equal(got, want), name
 
 
+def test_descriptors_of_many_elements(built, tmp_path):
+    """Beyond the 32 elements of round 1, up to the reference's own 100 (compile.c:49): a chain of
+    twelve hairpins (48 elements, 25 search levels: general instance) and one of 33 single bases
+    between two helices (lean descriptor, too many levels for the lean records) against the oracle."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(77)
+    s = _planted_sequence(rng, 30_000)
+    texts = ["parms\n\twc += gu;\ndescr\n" + "".join("\th5(minlen=2,maxlen=3)\n\t\tss(minlen=3,maxlen=4)\n\th3\n\tss(minlen=0,maxlen=2)\n" for _ in range(12)),
+             "descr\n\th5(minlen=3,maxlen=4)\n" + "".join("\t\tss(len=1)\n" for _ in range(33)) + "\th3\n\tss(minlen=1,maxlen=3)\n\th5(minlen=3,maxlen=3)\n\t\tss(minlen=3,maxlen=5)\n\th3\n"]
+    for k, text in enumerate(texts):
+        path = tmp_path / ("many%d.descr" % k)
+        path.write_text(text)
+        d = R.Descriptor(["-descr", str(path)])
+        assert d.n_elems > 32
+        sc = R.Scanner(d)
+        got = sc.scan(sc.database([s, s[:500]]))
+        want = oracle_scan(d, [s, s[:500]])
+        assert got.shape == want.shape and np.array_equal(got, want), text
+        assert k == 0 or want.shape[0] > 0
+
+
 def test_hit_dense_energy_sites(built, workdir, gbrna, tmp_path):
     """Many candidates per base: efn.descr (a tetraloop hairpin scored with efn()) and a hairpin
     without sequence constraint scored with efn() and efn2(), over the reference's test database
