@@ -1351,10 +1351,16 @@ RMD_GEN_FN bool rmd_gen_triplex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, 
 			if( cur - r.zero - 2 * hlen + 1 > stp.maxilen + stp1.maxilen + hlen )
 				continue;
 			r.hl = uint8_t( hlen );
-			r.a = int16_t( cur - stp1.minilen - hlen );		// first end of the middle strand, :821
+			// first end of the middle strand, :821 -- not beyond what the first interior's maximum
+			// allows (:833, tested by the reference after the match)
+			r.a = int16_t( cur - stp1.minilen - hlen );
+			if( stp.maxilen < ( 1 << 28 ) && r.a > r.zero + 2 * hlen - 1 + stp.maxilen )
+				r.a = int16_t( r.zero + 2 * hlen - 1 + stp.maxilen );
 			r.ph = 1;
 		}
-		const int	hlen = r.hl, last = r.zero + 2 * hlen + stp.minilen - 1;
+		const int	hlen = r.hl;
+		// ... and not below what the second interior's maximum allows (:835)
+		const int	last = rmd_imax( r.zero + 2 * hlen + stp.minilen - 1, stp1.maxilen < ( 1 << 28 ) ? cur - hlen - stp1.maxilen : -( 1 << 28 ) );
 		// middle strand ends whose base cannot complete the first triple are passed over
 		// (match_triplex :1198-1206 returns at once when the 5' end must be paired)
 		unsigned	m2 = 0x1f;
@@ -1430,24 +1436,53 @@ RMD_GEN_FN bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 		// ph == 2: find_4plex_inner :902, s1 upwards, s2 downwards
 		const int	hl = r.hl;
 		const int	s1lim = cur - 3 * hl - stp2.minilen - stp1.minilen;
-		// (s1, s2) whose bases cannot complete the first quad are passed over (match_4plex
-		// :1249-1257 returns at once when the 5' end must be paired)
-		const bool	prune = ( stp1.ends & RMA_5PAIRED ) && stp.tup >= 0;
-		const rmd_tup_t	&tup = rmd_tups( P )[ prune ? stp.tup : 0 ];
+		// The scan of (s1, s2), start of the second strand and end of the third, with what
+		// match_4plex() and the interior limits tested after it (:945-968) imply for each alone --
+		// necessary conditions, so only pairs that cannot be accepted are passed over:
+		//  * a quad holds only if its second base can complete it for some third (rmd_tup_t::q2);
+		//    quads after the first that cannot hold count against the mispair limit, the first
+		//    ends the match at once when the 5' end must be paired (:1249-1268);
+		//  * the same for the third base once the second strand is fixed (q3), first quad only
+		//    (the rest is match_4plex itself);
+		//  * interiors longer than their maxima: s1 beyond the first, s2 outside the other two.
+		const bool	masks = stp.tup >= 0, first5 = ( stp1.ends & RMA_5PAIRED ) != 0;
+		const rmd_tup_t	&tup = rmd_tups( P )[ masks ? stp.tup : 0 ];
+		const int	mplim = rmd_rules( P )[ stp1.rule ].tq_mplim[ hl ];
 		const int	b14 = rmd_code( sq, z + r.zero + hl - 1 ) * 5 + rmd_code( sq, z + cur - hl + 1 );
-		const unsigned	m2 = prune ? tup.q2[ b14 ] : 0x1fu;
-		while( r.a <= s1lim ){
+		const int	s2_first = cur - hl - stp2.minilen;
+		const int	big = 1 << 28;		// (an interior without upper limit: RMA_UNBOUNDED)
+		const int	s1_last = stp.maxilen < big ? rmd_imin( s1lim, r.zero + hl - 1 + stp.maxilen ) : s1lim;
+		while( r.a <= s1_last ){
 			if( RMD_TICK( st ) )
 				return false;
 			const int	s1 = r.a;
 			const int	b2 = rmd_code( sq, z + s1 );
-			if( r.c < s1 + 2 * hl + stp1.minilen || !( ( m2 >> b2 ) & 1 ) ){
+			if( r.c == s2_first && masks ){
+				// arriving at this s1: can the second strand stand at all?
+				int	bad = 0;
+				bool	ok = true;
+				for( int q = 0; q < hl && ok; q++ ){
+					const unsigned	m = tup.q2[ rmd_code( sq, z + r.zero + hl - 1 - q ) * 5 + rmd_code( sq, z + cur - hl + 1 + q ) ];
+					if( !( ( m >> rmd_code( sq, z + s1 + q ) ) & 1 ) )
+						ok = q == 0 ? !first5 : ++bad <= mplim;
+				}
+				if( !ok ){
+					r.a++;
+					continue;
+				}
+			}
+			// s2 from the top of what the third interior's maximum allows down to what the second's and the
+			// strands' room allow
+			const int	s2_lo = stp2.maxilen < big ? rmd_imax( s1 + 2 * hl + stp1.minilen, cur - hl + 1 - stp2.maxilen ) : s1 + 2 * hl + stp1.minilen;
+			if( stp1.maxilen < big && r.c > s1 + 2 * hl - 1 + stp1.maxilen )
+				r.c = int16_t( s1 + 2 * hl - 1 + stp1.maxilen );
+			if( r.c < s2_lo ){
 				r.a++;
-				r.c = int16_t( cur - hl - stp2.minilen );
+				r.c = int16_t( s2_first );
 				continue;
 			}
 			const int	s2 = r.c--;
-			if( prune && !( ( tup.q3[ ( b14 / 5 * 5 + b2 ) * 5 + b14 % 5 ] >> rmd_code( sq, z + s2 ) ) & 1 ) )
+			if( masks && first5 && !( ( tup.q3[ ( b14 / 5 * 5 + b2 ) * 5 + b14 % 5 ] >> rmd_code( sq, z + s2 ) ) & 1 ) )
 				continue;
 			int	n_mpr, mm1 = 0, mm2 = 0;
 			if( !rmd_match_4plex( P, sq, d1, d2, z + r.zero, z + s1, z + s2, z + cur, hl, &n_mpr, &mm1, &mm2 ) )
