@@ -287,6 +287,16 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		}
 		out->split_s = run >= 1 && run <= 4 && more ? run - 1 : -1;
 	}
+	{
+		int	o = 0;
+		for( int s = 0; s < p->n_searches; s++ ){
+			const rmd_elem_t	&e = out->elems[ p->searches[ s ] ];
+			const bool	single = s > 0 && e.type == RMA_T_SS && !e.loop;
+			out->rec_off[ s ] = int16_t( single ? ( o | 0x8000 ) : o );
+			o += single ? 1 : 3;
+		}
+		out->n_rec_dwords = o;
+	}
 	// first-tuple masks of the triplex / 4-plex pair tables
 	int	n_tups = 0;
 	for( int d = 0; d < p->n_elems; d++ )

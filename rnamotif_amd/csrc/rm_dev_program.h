@@ -159,6 +159,11 @@ struct rmd_program_t {
 	int32_t	n_regexes, n_rules, n_pairsets, n_pks, n_tups;
 	int32_t	off_regexes, off_rules, off_pairsets, off_pks, off_tups;
 	int32_t	image_bytes;
+	// general path, records in LDS (rm_scan_hip.hip LdsGRecs): dword offset of level k's record; a
+	// level with a single alternative (rmd_elem_t::back_s) keeps its window only -- one dword,
+	// marked by the sign bit -- the others three
+	int16_t	rec_off[ RMD_MAX_ELEMS ];
+	int32_t	n_rec_dwords;
 	int8_t	searches[ RMD_MAX_ELEMS ];
 	rmd_elem_t	lctx, rctx;
 	rmd_site_t	sites[ RMD_MAX_SITES ];

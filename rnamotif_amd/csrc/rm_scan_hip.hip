@@ -126,27 +126,40 @@ struct LdsRecs {
 template< int BLOCK >
 struct LdsGRecs {
 	uint32_t	*w;
+	// levels up to the split level: the iterator each one's alternative was resumed from (rmd_gen_step)
+	uint32_t	*bw;
+	// rmd_program_t::rec_off (in LDS): where level k's record starts; levels with a single
+	// alternative keep the window dword only (their iterator is "the whole window, taken")
+	const int16_t	*off;
 	__device__ inline rmd_grec_t	get( int k ) const
 	{
-		const uint32_t	d0 = w[ ( 3 * k ) * BLOCK ], d1 = w[ ( 3 * k + 1 ) * BLOCK ], d2 = w[ ( 3 * k + 2 ) * BLOCK ];
+		const int	o = off[ k ];
+		const uint32_t	d0 = w[ ( o & 0x7fff ) * BLOCK ];
 		rmd_grec_t	r;
 		r.zero = int16_t( d0 & 0xffffu );
 		r.osd = int16_t( d0 >> 16 );
-		r.sd = int16_t( d1 & 0xffffu );
-		r.a = int16_t( d1 >> 16 );
-		r.c = int16_t( d2 & 0xffffu );
-		r.hl = uint8_t( ( d2 >> 16 ) & 0xffu );
-		r.ph = uint8_t( d2 >> 24 );
+		if( o < 0 ){
+			r.sd = int16_t( r.osd - 1 );
+			r.a = r.c = 0;
+			r.hl = 0;
+			r.ph = 1;
+			return r;
+		}
+		rmd_grec_set_words( r, w[ ( o + 1 ) * BLOCK ], w[ ( o + 2 ) * BLOCK ] );
 		return r;
 	}
-	__device__ inline void	set_iter( int k, rmd_grec_t v )
+	__device__ inline void	set_iter_words( int k, uint32_t d1, uint32_t d2 )
 	{
-		w[ ( 3 * k + 1 ) * BLOCK ] = rmd_grec_word1( v );
-		w[ ( 3 * k + 2 ) * BLOCK ] = rmd_grec_word2( v );
+		const int	o = off[ k ];
+		if( o >= 0 ){
+			w[ ( o + 1 ) * BLOCK ] = d1;
+			w[ ( o + 2 ) * BLOCK ] = d2;
+		}
 	}
+	__device__ inline void	set_iter( int k, rmd_grec_t v ) { set_iter_words( k, rmd_grec_word1( v ), rmd_grec_word2( v ) ); }
 	__device__ inline void	set_window( int k, int zero, int osd )
 	{
-		w[ ( 3 * k ) * BLOCK ] = ( uint32_t( zero ) & 0xffffu ) | ( uint32_t( osd ) << 16 );
+		w[ ( off[ k ] & 0x7fff ) * BLOCK ] = ( uint32_t( zero ) & 0xffffu ) | ( uint32_t( osd ) << 16 );
 	}
 	__device__ inline void	set( int k, rmd_grec_t v )
 	{
@@ -155,28 +168,21 @@ struct LdsGRecs {
 	}
 	__device__ inline void	set_zero( int k, int zero )
 	{
-		uint32_t	&d0 = w[ ( 3 * k ) * BLOCK ];
+		uint32_t	&d0 = w[ ( off[ k ] & 0x7fff ) * BLOCK ];
 		d0 = ( d0 & 0xffff0000u ) | ( uint32_t( zero ) & 0xffffu );
 	}
 	__device__ inline void	set_osd( int k, int osd )
 	{
-		uint32_t	&d0 = w[ ( 3 * k ) * BLOCK ];
+		uint32_t	&d0 = w[ ( off[ k ] & 0x7fff ) * BLOCK ];
 		d0 = ( d0 & 0xffffu ) | ( uint32_t( osd ) << 16 );
 	}
-	__device__ inline int	hl( int k ) const { return int( ( w[ ( 3 * k + 2 ) * BLOCK ] >> 16 ) & 0xffu ); }
-	// levels up to the split level: the iterator each one's alternative was resumed from (rmd_gen_step)
-	uint32_t	*bw;
+	__device__ inline int	hl( int k ) const { return int( ( w[ ( off[ k ] + 2 ) * BLOCK ] >> 16 ) & 0xffu ); }	// (helix levels only)
 	__device__ inline void	set_before( int k, rmd_grec_t v )
 	{
 		bw[ ( 2 * k ) * BLOCK ] = rmd_grec_word1( v );
 		bw[ ( 2 * k + 1 ) * BLOCK ] = rmd_grec_word2( v );
 	}
 	__device__ inline uint32_t	before_word( int i ) const { return bw[ i * BLOCK ]; }
-	__device__ inline void	set_iter_words( int k, uint32_t d1, uint32_t d2 )
-	{
-		w[ ( 3 * k + 1 ) * BLOCK ] = d1;
-		w[ ( 3 * k + 2 ) * BLOCK ] = d2;
-	}
 };
 
 // rmd_gen_step()'s hand-over of the alternatives of the split level: a queue of continuations in
@@ -351,7 +357,7 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 	uint32_t	*const g_deep = gt.deep;
 	int	&s_qhead = *gt.qhead, &s_dqn = *gt.dqn, &s_dqhead = *gt.dqhead;
 	const HitBuf	&hb = sink.hb;
-	LdsGRecs<BLOCK>	gr{ gt.recs + threadIdx.x, gt.before + threadIdx.x };
+	LdsGRecs<BLOCK>	gr{ gt.recs + threadIdx.x, gt.before + threadIdx.x, P->rec_off };
 	rmd_seq_t	sq{ tile, p_lo };
 	rmd_lane_t	lane;
 	int	k = -1;
@@ -522,9 +528,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// (the general instance's records take the same place; behind them the resume states of the
 	// levels up to the split level and the queue of continuations)
 	const int	split_s = LEAN || ( dbg & 256 ) ? -1 : P->split_s;
-	uint32_t	*const g_before = lean_lo + 3 * P->n_searches * BLOCK;
+	uint32_t	*const g_before = lean_lo + ( LEAN ? 0 : P->n_rec_dwords ) * BLOCK;
 	uint32_t	*const g_deep = g_before + 2 * ( split_s + 1 ) * BLOCK;
-	LdsGRecs<BLOCK>	gr{ lean_lo + threadIdx.x, g_before + threadIdx.x };
+	LdsGRecs<BLOCK>	gr{ lean_lo + threadIdx.x, g_before + threadIdx.x, P->rec_off };
 	const bool	lit = P->lit_re >= 0 && !( dbg & 8 );
 	const int	lit_n = lit ? rmd_regexes( P )[ P->lit_re ].n_states : 0;
 	const int	lit_hi = lit ? ( P->lit_hi < w - lit_n ? P->lit_hi : w - lit_n ) : 0;
@@ -1114,7 +1120,7 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
-	lds += size_t( dp.n_searches ) * 256 * ( lean ? LEAN_REC_BYTES : GEN_REC_BYTES );
+	lds += lean ? size_t( dp.n_searches ) * 256 * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * 256 * 4;
 	if( !lean && dp.split_s >= 0 )		// resume states of the levels up to the split level, queue of continuations
 		lds += size_t( dp.split_s + 1 ) * 256 * 8 + size_t( DEEP_QUEUE ) * ( 2 + 2 * ( dp.split_s + 1 ) ) * 4;
 	return lds;
