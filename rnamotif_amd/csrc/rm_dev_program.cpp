@@ -72,7 +72,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		FAIL( "too many seq= expressions for the device scanner" );
 	out->n_elems = p->n_elems;
 	out->n_searches = p->n_searches;
-	out->step_budget = 32;
+	out->step_budget = 128;	// (32 .. 128 measure alike, profiles/matrix_r2.sh; with levels chained within a step the longer one is ahead)
 	out->dminlen = p->dminlen;
 	out->w_winsize = p->dmaxlen < p->windowsize ? p->dmaxlen : p->windowsize;
 	out->strict_helices = p->strict_helices;

@@ -1706,41 +1706,55 @@ struct rmd_no_split_t {
 // element has a single alternative take no transition of their own: they are checked on the way
 // down (rmd_gen_descend) and skipped on the way back (rmd_elem_t::back_s), so a lane spends its
 // steps on the levels that have a choice -- and so do the lanes next to it.
+// A step goes on across levels while its budget lasts (chain): down into the level an
+// alternative opens, back to the level below when one is exhausted -- a lane that alternates
+// between two levels (an ss of several lengths and the helix behind it) does not need a round
+// for each visit.  It hands back at a level <= floor (the continuation's end, rmd_gen_resume).
 template< class GR, class Sink, class Accel = rmd_no_ends_t, class Split = rmd_no_split_t >
 RMD_FN int rmd_gen_step( const rmd_program_t *P, GR &gr, rmd_gen_t &st, const rmd_seq_t &sq, int k, rmd_lane_t *L, Sink &sink,
-	const Accel &accel = Accel(), const Split &split = Split() )
+	const Accel &accel = Accel(), const Split &split = Split(), int floor = -1, bool chain = true )
 {
-	const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
 	const int	S = split.level();
-	rmd_grec_t	r = gr.get( k );
 	st.budget = st.budget0;
 	st.paused = 0;
 	for( ; ; ){
-		if( S >= 0 && k <= S )
-			gr.set_before( k, r );		// what this alternative's generator is resumed from
-		if( !rmd_gen_next( P, gr, st, sq, k, stp, r, accel ) ){
-			if( !st.paused )
-				return stp.back_s;
-			gr.set_iter( k, r );		// out of budget: the level goes on from here at its next step
-			return k;
+		const rmd_elem_t	&stp = P->elems[ P->searches[ k ] ];
+		rmd_grec_t	r = gr.get( k );
+		int	next;
+		for( ; ; ){
+			if( S >= 0 && k <= S )
+				gr.set_before( k, r );		// what this alternative's generator is resumed from
+			if( !rmd_gen_next( P, gr, st, sq, k, stp, r, accel ) ){
+				if( st.paused ){
+					gr.set_iter( k, r );	// out of budget: the level goes on from here at its next step
+					return k;
+				}
+				next = stp.back_s;
+				break;
+			}
+			gr.set_iter( k, r );
+			const int	j = rmd_gen_descend( P, gr, st, sq, k );
+			if( j < 0 )
+				continue;		// this alternative of level k leads nowhere: its next one
+			if( k == S ){
+				// an alternative of the split level: numbered, and walked by whoever takes the continuation
+				const int	alt = st.order++;
+				if( j < P->n_searches && split.push( st, gr, alt ) )
+					continue;
+				st.tag = alt;
+			}
+			if( j < P->n_searches ){
+				rmd_gen_open( P, gr, j );
+				next = j;
+				break;
+			}
+			rmd_gen_emit<Accel::kinds>( P, gr, st, sq, L, sink );
+			if( !chain || st.budget <= 0 )
+				return k;
 		}
-		gr.set_iter( k, r );
-		const int	j = rmd_gen_descend( P, gr, st, sq, k );
-		if( j < 0 )
-			continue;		// this alternative of level k leads nowhere: its next one
-		if( k == S ){
-			// an alternative of the split level: numbered, and walked by whoever takes the continuation
-			const int	alt = st.order++;
-			if( j < P->n_searches && split.push( st, gr, alt ) )
-				continue;
-			st.tag = alt;
-		}
-		if( j < P->n_searches ){
-			rmd_gen_open( P, gr, j );
-			return j;
-		}
-		rmd_gen_emit<Accel::kinds>( P, gr, st, sq, L, sink );
-		return k;
+		if( !chain || next <= floor || st.budget <= 0 )
+			return next;
+		k = next;
 	}
 }
 

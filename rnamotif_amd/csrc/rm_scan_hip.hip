@@ -434,9 +434,9 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 					}
 					if( k >= 0 && k == serve ){
 						if( round == 0 )
-							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends, split );
+							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends, split, -1, !( dbg & 512 ) );
 						else{
-							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends );
+							k = rmd_gen_step( P, gr, st, sq, k, &lane, sink, ends, rmd_no_split_t(), split_s, !( dbg & 512 ) );
 							if( k <= split_s )
 								k = -1;		// back at the split level: this alternative is done
 						}

@@ -156,7 +156,7 @@ static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t
 			memset( &recs, 0x55, sizeof( recs ) );
 			k = rmd_gen_resume( dp, recs, st, sq, szero, slen, r0, cnt, dp->split_s, c.before, c.alt, ends );
 			while( k > dp->split_s )
-				k = rmd_gen_step( dp, recs, st, sq, k, lane, tmp, ends );
+				k = rmd_gen_step( dp, recs, st, sq, k, lane, tmp, ends, rmd_no_split_t(), dp->split_s );
 		}
 		const int	stride = sink.stride;
 		std::vector<int>	idx( mine.size() / stride );
