@@ -125,6 +125,13 @@ int	rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **hits, int64
 int	rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
 		float *efn_ms, char *err, size_t errlen );
 
+/* Records from several scans (the slices of one database searched by several GPUs or hosts, word 0
+ * already the database-wide entry number) into the reference's output order: by the five header
+ * words, ties in the order given; the order word is renumbered within (entry, strand, start, rank).
+ * out[n][stride] must not overlap hits.  Host only -- what rank 0 of mrnamotif does with the
+ * MT_RESULT messages it receives (mrnamotif.c:733-760). */
+int	rma_sort_hits( const int32_t *hits, int64_t n_hits, int32_t stride, int32_t *out, char *err, size_t errlen );
+
 /* ---- replay: run the score program over candidates and print accepted hits
  * in the reference's format to a stdio stream opened on path ("-" = stdout). */
 int	rma_replay_open( rma_descr_t *d, const char *path, rma_replay_t **out, char *err, size_t errlen );

@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
     L.rma_pack_read.argtypes = [cpp, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_db_create_packed_ranges.argtypes = [vp, vp, i32p, i32p, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_replay_pack.argtypes = [vp, vp, C.c_int32, i32p, C.c_int64, i64p, C.c_char_p, C.c_size_t]
+    L.rma_sort_hits.argtypes = [i32p, C.c_int64, C.c_int32, i32p, C.c_char_p, C.c_size_t]
     L.rma_pack_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_pack_close.argtypes = [vp]
     L.rma_pack_count.argtypes = [vp]
@@ -301,6 +302,19 @@ class Replay:
             rc = lib().rma_replay_close(self._h, err, _ERRLEN)
             self._h = None
             _check(rc, err)
+
+
+def sort_hits(hits: np.ndarray) -> np.ndarray:
+    """Hit records [n, stride] (from several scans, word 0 the database-wide entry number) in the
+    reference's output order, order word renumbered: rma_sort_hits()."""
+    h = np.ascontiguousarray(hits, dtype=np.int32)
+    if h.ndim != 2:
+        raise ValueError("hit records are [n, stride]")
+    out = np.empty_like(h)
+    err = C.create_string_buffer(512)
+    i32p = C.POINTER(C.c_int32)
+    _check(lib().rma_sort_hits(h.ctypes.data_as(i32p), h.shape[0], h.shape[1], out.ctypes.data_as(i32p), err, len(err)), err)
+    return out
 
 
 def read_fasta(path: str) -> List[Tuple[bytes, bytes, bytes]]:

@@ -6,6 +6,7 @@
 #include "rm_efndata.h"
 #include "rm_pack.h"
 #include "rm_stream.h"
+#include "rm_hitsort.h"
 #include <cctype>
 #include <cstddef>
 #include <cstring>
@@ -138,6 +139,19 @@ extern "C" int rma_replay_pack( rma_replay_t *rp, const rma_pack_t *pk, int32_t 
 		fflush( rp->fp );
 		return 0;
 	}catch( rma::Error &e ){
+		return set_err( err, errlen, e.what() );
+	}
+}
+
+extern "C" int rma_sort_hits( const int32_t *hits, int64_t n_hits, int32_t stride, int32_t *out, char *err, size_t errlen )
+{
+	if( n_hits < 0 || n_hits > int64_t( 0xffffffffu ) || stride < 5 || ( n_hits && ( !hits || !out ) ) )
+		return set_err( err, errlen, "rma_sort_hits: records of at least 5 words, at most 2^32-1 of them" );
+	try{
+		std::vector<rma::HitKey>	keys, tmp;
+		rma::sort_hits( hits, n_hits, stride, out, keys, tmp );
+		return 0;
+	}catch( std::exception &e ){
 		return set_err( err, errlen, e.what() );
 	}
 }

@@ -34,6 +34,8 @@
 #include "rm_efn2_core.h"
 #include "rm_fasta.h"
 #include "rm_pack.h"
+#include "rm_hitsort.h"
+#include "rm_hitsort_dev.h"
 #include "rnamotif_amd.h"
 
 // ---------------------------------------------------------------- device views
@@ -1047,6 +1049,9 @@ struct rma_scanner {
 	int32_t	*h_raw = nullptr;		// pinned
 	size_t	h_raw_cap = 0;
 	std::vector<int32_t>	h_sorted;
+	std::vector<rma::HitKey>	keys, keys_tmp;
+	rma::DevHitSort	dsort;		// ordering on the device (rm_hitsort_dev.h)
+	unsigned long long	*h_ctr = nullptr;	// pinned: the counters a launch leaves
 	int	tile_t = 2048;
 	int	grid_blocks = 0;
 };
@@ -1059,7 +1064,7 @@ struct rma_db {
 	int32_t	*d_tile_seq = nullptr;
 	int	tile_t = 0, qcap = 0, group = 1;	// launch shape of this database (see db_upload)
 	int32_t	*d_slen = nullptr, *d_pos_lo = nullptr, *d_pos_hi = nullptr;
-	int32_t	n_seq = 0;
+	int32_t	n_seq = 0, max_slen = 0;
 	int64_t	n_tiles = 0, total_bases = 0;
 	int	strands = 2;
 };
@@ -1281,6 +1286,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	// size (count-then-emit, rma_scan_device)
 	sc->hit_cap = 1 << 17;
 	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
+	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_ctr ), 4 * sizeof( unsigned long long ), hipHostMallocDefault ) );
 	guard.p = nullptr;
 	*out = sc;
 	return 0;
@@ -1308,6 +1314,9 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 	( void )hipFree( sc->d_efn2 );
 	if( sc->h_raw != nullptr )
 		( void )hipHostFree( sc->h_raw );
+	if( sc->h_ctr != nullptr )
+		( void )hipHostFree( sc->h_ctr );
+	sc->dsort.release();
 	( void )hipFree( sc->d_t16 );
 	( void )hipFree( sc->d_tlkey );
 	( void )hipFree( sc->d_loginc );
@@ -1353,8 +1362,10 @@ static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_wo
 	db->group = 1;
 	{
 		int64_t	tot = 0;
-		for( int i = 0; i < n; i++ )
+		for( int i = 0; i < n; i++ ){
 			tot += slen[ i ];
+			db->max_slen = std::max( db->max_slen, slen[ i ] );
+		}
 		bool	grouped = n >= 64 && tot / n < SHORT_ENTRY_MEAN && !getenv( "RNAMOTIF_TILE" );
 		if( const char *force = getenv( "RNAMOTIF_SHORT" ) )	// "0" never, "1" always (tests)
 			grouped = force[ 0 ] == '1';
@@ -1529,8 +1540,10 @@ static DbView view_of( const rma_scanner *sc, const rma_db *db )
 	return v;
 }
 
-extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
-	float *efn_ms, char *err, size_t errlen )
+// wait = false: the efn kernel is left running on the scanner's stream (rma_scan() queues the ordering
+// and the copy back behind it and waits once)
+static int scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
+	float *efn_ms, char *err, size_t errlen, bool wait )
 {
 	constexpr int	BLOCK = 256;
 	HIPCHK( hipSetDevice( sc->device ) );
@@ -1584,8 +1597,10 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 			sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
-		HIPCHK( hipMemcpyAsync( &count, sc->d_counters, sizeof( count ), hipMemcpyDeviceToHost, sc->stream ) );
+		// [0] candidates, [3] queue overflow of the general instance: one copy, one wait
+		HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->d_counters, 4 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, sc->stream ) );
 		HIPCHK( hipStreamSynchronize( sc->stream ) );
+		count = sc->h_ctr[ 0 ];
 		if( getenv( "RNAMOTIF_DBG" ) ){
 			unsigned long long	q = 0;
 			( void )hipMemcpy( &q, sc->d_counters + 2, sizeof( q ), hipMemcpyDeviceToHost );
@@ -1608,8 +1623,7 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 		}
 		if( !lean ){
 			// the general instance does not search queue overflow in place: a larger spill area, and again
-			unsigned long long	need = 0;
-			HIPCHK( hipMemcpy( &need, sc->d_counters + 3, sizeof( need ), hipMemcpyDeviceToHost ) );
+			const unsigned long long	need = sc->h_ctr[ 3 ];
 			if( need > 0 ){
 				if( attempt == 3 ){
 					snprintf( err, errlen, "work queue overflow after regrow (%llu items in a tile)", need );
@@ -1647,11 +1661,18 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 			sc->d_efn2 );
 		HIPCHK( hipGetLastError() );
 		HIPCHK( hipEventRecord( sc->ev[ 3 ], sc->stream ) );
-		HIPCHK( hipStreamSynchronize( sc->stream ) );
+		if( wait || efn_ms )
+			HIPCHK( hipStreamSynchronize( sc->stream ) );
 		if( efn_ms )
 			HIPCHK( hipEventElapsedTime( efn_ms, sc->ev[ 2 ], sc->ev[ 3 ] ) );
 	}
 	return 0;
+}
+
+extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
+	float *efn_ms, char *err, size_t errlen )
+{
+	return scan_device( sc, db, n_hits, search_ms, efn_ms, err, errlen, true );
 }
 
 extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **hits, int64_t *n_hits,
@@ -1668,9 +1689,9 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 			t0 = t1;
 		}
 	};
-	if( rma_scan_device( sc, db, &n, nullptr, nullptr, err, errlen ) )
+	if( scan_device( sc, db, &n, nullptr, nullptr, err, errlen, false ) )
 		return 1;
-	lap( "kernels" );
+	lap( "search" );
 	*n_hits = n;
 	if( n == 0 )
 		return 0;
@@ -1685,39 +1706,37 @@ extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **
 		HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_raw ), words * 2 * sizeof( int32_t ), hipHostMallocDefault ) );
 		sc->h_raw_cap = words * 2;
 	}
+	// Reference order -- (entry, strand, start, rank, order), order word renumbered -- on the device,
+	// behind the efn kernel on the same stream: what comes back is the final stream (rm_hitsort_dev.h).
+	// Header words that do not fit the 64-bit key (or RNAMOTIF_HOSTSORT=1): the host's sort_hits().
+	const bool	host_sort = getenv( "RNAMOTIF_HOSTSORT" ) != nullptr && atoi( getenv( "RNAMOTIF_HOSTSORT" ) ) != 0;
+	bool	on_device = false;
+	if( !host_sort && n >= 2 ){
+		auto	bits_of = []( unsigned x ){ int b = 0; while( x ){ b++; x >>= 1; } return b; };
+		if( sc->dsort.reserve( sc->hit_cap, stride ) == hipSuccess &&
+			sc->dsort.run( sc->d_hits, n, bits_of( unsigned( db->n_seq > 0 ? db->n_seq - 1 : 0 ) ), bits_of( unsigned( db->max_slen ) ),
+				bits_of( unsigned( sc->dprog.w_winsize ) ), sc->stream ) == hipSuccess ){
+			int	flag = 1;
+			HIPCHK( hipMemcpyAsync( sc->h_raw, sc->dsort.d_out, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
+			HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->dsort.d_flag, sizeof( int ), hipMemcpyDeviceToHost, sc->stream ) );
+			HIPCHK( hipStreamSynchronize( sc->stream ) );
+			memcpy( &flag, sc->h_ctr, sizeof( flag ) );
+			on_device = flag == 0;
+			if( !on_device && sc->dsort.w_ord < 31 )
+				sc->dsort.w_ord = 31;	// (order words above 255: room for them from now on, if the other fields leave it)
+		}else
+			( void )hipGetLastError();
+	}
+	if( on_device ){
+		lap( "ordered" );
+		*hits = sc->h_raw;
+		return 0;
+	}
 	HIPCHK( hipMemcpyAsync( sc->h_raw, sc->d_hits, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
 	HIPCHK( hipStreamSynchronize( sc->stream ) );
 	lap( "copy back" );
-	// reference order: (seq, comp, szero, rank, order)
-	// the five header words (all >= 0) as two 64-bit keys
-	struct Key { uint64_t a, b; int64_t i; };
-	const int32_t	*d = sc->h_raw;
-	std::vector<Key>	keys( static_cast<size_t>( n ) );
-	for( int64_t i = 0; i < n; i++ ){
-		const int32_t	*x = d + i * stride;
-		keys[ i ].a = ( uint64_t( uint32_t( x[ 0 ] ) ) << 32 ) | ( uint64_t( uint32_t( x[ 1 ] ) & 1u ) << 31 ) | uint32_t( x[ 2 ] );
-		keys[ i ].b = ( uint64_t( uint32_t( x[ 3 ] ) ) << 32 ) | uint32_t( x[ 4 ] );
-		keys[ i ].i = i;
-	}
-	lap( "keys" );
-	// (a lane emits the candidates of one alternative in the reference's order and its slots in
-	// the hit buffer ascend: equal keys -- candidates of one continuation -- stay in buffer order)
-	std::sort( keys.begin(), keys.end(), []( const Key &x, const Key &y ){
-		return x.a != y.a ? x.a < y.a : x.b != y.b ? x.b < y.b : x.i < y.i; } );
-	lap( "sort" );
 	sc->h_sorted.resize( words );
-	// the order word becomes what the reference's walk would count: 0, 1, ... within (entry, strand, start, rank)
-	uint64_t	pa = ~0ull;
-	uint32_t	prank = 0, order = 0;
-	for( int64_t i = 0; i < n; i++ ){
-		int32_t	*o = &sc->h_sorted[ size_t( i ) * stride ];
-		memcpy( o, d + keys[ i ].i * stride, stride * sizeof( int32_t ) );
-		const uint32_t	rank = uint32_t( keys[ i ].b >> 32 );
-		order = ( keys[ i ].a == pa && rank == prank ) ? order + 1 : 0;
-		pa = keys[ i ].a;
-		prank = rank;
-		o[ 4 ] = int32_t( order );
-	}
+	rma::sort_hits( sc->h_raw, n, stride, sc->h_sorted.data(), sc->keys, sc->keys_tmp );
 	lap( "ordering" );
 	*hits = sc->h_sorted.data();
 	return 0;

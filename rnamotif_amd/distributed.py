@@ -137,13 +137,9 @@ def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int
 
 
 def sort_hits(allh: np.ndarray) -> np.ndarray:
-    """Records by (seq, comp, szero, rank, order) = the reference's output order.  Ranks that
-    hold consecutive runs of entries deliver an already ordered concatenation: checked first."""
+    """Records by (seq, comp, szero, rank, order) = the reference's output order: the library's
+    rma_sort_hits() (host code, the same sort a single scan ends with)."""
     if allh.shape[0] < 2:
         return allh
-    k = allh[:, :5].astype(np.uint64)
-    a = (k[:, 0] << np.uint64(32)) | ((k[:, 1] & np.uint64(1)) << np.uint64(31)) | k[:, 2]
-    b = (k[:, 3] << np.uint64(32)) | k[:, 4]
-    if bool(np.all((a[1:] > a[:-1]) | ((a[1:] == a[:-1]) & (b[1:] >= b[:-1])))):
-        return allh
-    return allh[np.lexsort((b, a))]
+    from . import sort_hits as _sort
+    return _sort(allh)
