@@ -1,0 +1,26 @@
+"""Wave-cycle shares of the search kernel's phases (RNAMOTIF_DBG=32 counters) for a descriptor over
+the bench database.  python profiles/phases.py [descr ...]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rnamotif_amd as R  # noqa: E402
+
+os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
+names = sys.argv[1:] or ["trna.descr"]
+HERE = os.getcwd()
+seqs = R.synthetic_records(100)
+os.chdir(os.path.join(ROOT, "tests", "golden", "descr"))
+for name in names:
+    d = R.Descriptor(["-descr", name])
+    sc = R.Scanner(d)
+    db = sc.database(seqs)
+    sc.scan_device(db)
+    print("==", name, "search %.3f ms" % sc.scan_device(db)[1], flush=True)
+    os.environ["RNAMOTIF_DBG"] = "34"
+    sc.scan_device(db)
+    sys.stderr.flush()
+    del os.environ["RNAMOTIF_DBG"]
+    db.close()
+    sc.close()

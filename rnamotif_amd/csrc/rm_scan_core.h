@@ -63,6 +63,23 @@ struct rmd_seq_t {
 
 RMD_FN int rmd_code( const rmd_seq_t &s, int p ) { return s.sq[ p - s.sq0 ]; }
 
+// A window of a strand as 4-bit codes, 8 per dword in forward-strand order, dwords STRIDE apart
+// (the pooled pass B of the kernel keeps one column per lane in LDS; the bases come straight from
+// the packed database, complemented for the other strand).  Position p of the strand is nibble
+// ( p ^ flip ) + bias: flip 0 / bias -first for the forward strand, flip -1 / bias slen - first
+// for the reverse one (~p = -p - 1).
+template< int STRIDE >
+struct rmd_nibseq_t {
+	const uint32_t	*w;
+	int32_t	flip, bias;
+};
+template< int STRIDE >
+RMD_FN int rmd_code( const rmd_nibseq_t<STRIDE> &s, int p )
+{
+	const int	i = ( p ^ s.flip ) + s.bias;
+	return int( ( s.w[ ( i >> 3 ) * STRIDE ] >> ( ( i & 7 ) * 4 ) ) & 15u );
+}
+
 RMD_FN int rmd_paired( const rmd_program_t *P, int ps, int b5, int b3 )		// RM_paired :1291
 {
 	return ( rmd_pairsets( P )[ ps ].mat2 >> ( b5 * 5 + b3 ) ) & 1;
@@ -114,7 +131,8 @@ RMD_FN uint64_t rmd_re_close( const rmd_regex_t &re, uint64_t f )
 	return f;
 }
 
-RMD_COLD int rmd_re_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len )
+template< class SQ >
+RMD_COLD int rmd_re_step( const rmd_regex_t &re, const SQ &sq, int off, int len )
 {
 	uint64_t	act = 0, endbit = 1ull << re.n_states;
 	for( int pos = 0; ; pos++ ){
@@ -134,7 +152,8 @@ RMD_COLD int rmd_re_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, i
 
 // mm_step()/mm_advance() (mm_regexp.c:353-469): fixed length expressions only.
 // *n_mm is left as the last attempt left it.
-RMD_COLD int rmd_re_mm_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off, int len, int l_mm, int *n_mm )
+template< class SQ >
+RMD_COLD int rmd_re_mm_step( const rmd_regex_t &re, const SQ &sq, int off, int len, int l_mm, int *n_mm )
 {
 	int	n = re.n_states;
 	for( int st = 0; ; st++ ){
@@ -165,7 +184,8 @@ RMD_COLD int rmd_re_mm_step( const rmd_regex_t &re, const rmd_seq_t &sq, int off
 }
 
 // chk_seq(), find_motif.c:1810
-RMD_FN int rmd_chk_seq( const rmd_program_t *P, const rmd_elem_t &e, const rmd_seq_t &sq, int off, int len, int *n_mm )
+template< class SQ >
+RMD_FN int rmd_chk_seq( const rmd_program_t *P, const rmd_elem_t &e, const SQ &sq, int off, int len, int *n_mm )
 {
 	const rmd_regex_t	&re = rmd_regexes( P )[ e.re ];
 	if( e.mismatch > 0 )
@@ -176,7 +196,8 @@ RMD_FN int rmd_chk_seq( const rmd_program_t *P, const rmd_elem_t &e, const rmd_s
 // Necessary condition for chk_seq( e, s5, len ) with any len >= e.minlen: the
 // leading mandatory positions of an anchored seq= must accept the bases at s5.
 // Used to drop start positions before any search state is touched.
-RMD_FN int rmd_prefix_ok( const rmd_program_t *P, const rmd_elem_t &e, const rmd_seq_t &sq, int s5 )
+template< class SQ >
+RMD_FN int rmd_prefix_ok( const rmd_program_t *P, const rmd_elem_t &e, const SQ &sq, int s5 )
 {
 	if( e.re < 0 || e.mismatch > 0 )
 		return 1;
@@ -192,7 +213,8 @@ RMD_FN int rmd_prefix_ok( const rmd_program_t *P, const rmd_elem_t &e, const rmd
 // match_wchlx(), find_motif.c:975.  Every candidate ends at s3, so the result
 // is the set of accepted lengths (bit hl of *cand) and the mispair positions.
 // mm5/mm3: s_n_mismatches of the two strands, in (current value) and out.
-RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const rmd_seq_t &sq,
+template< class SQ >
+RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis, int *pmm5, int *pmm3 )
 {
 	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
@@ -369,7 +391,8 @@ RMD_COLD int rmd_match_4plex( const rmd_program_t *P, const rmd_seq_t &sq,
 // Does match_wchlx( s5, s3 ) have any candidate, seq= constraints aside?  A
 // superset test for the pre-filter pass: same pairing, end and pairfrac rules
 // (find_motif.c:1010-1109), no state written.
-RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const rmd_seq_t &sq, int s5, int s3, int s3lim )
+template< class SQ >
+RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const SQ &sq, int s5, int s3, int s3lim )
 {
 	if( stp.minlen == 0 )
 		return 1;
@@ -409,7 +432,8 @@ RMD_FN int rmd_wtype( const rmd_program_t *P, const rmd_lane_t *L, int pos, int 
 	return undef_is_ss ? RMA_T_SS : -1;
 }
 
-RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_motif :1406
+template< class SQ >
+RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const SQ &sq )	// chk_motif :1406
 {
 	for( int d = 0; d < P->n_elems; d++ ){
 		const rmd_elem_t	&stp = P->elems[ d ];
@@ -472,7 +496,8 @@ RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const r
 	return 1;
 }
 
-RMD_COLD int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const rmd_seq_t &sq )	// set_context :1720
+template< class SQ >
+RMD_COLD int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const SQ &sq )	// set_context :1720
 {
 	if( P->has_lctx ){
 		int	off = L->moff[ 0 ] - P->lctx.maxlen;
@@ -507,7 +532,8 @@ RMD_COLD int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const rmd_s
 	return 1;
 }
 
-RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const rmd_seq_t &sq )	// chk_sites :1758
+template< class SQ >
+RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const SQ &sq )	// chk_sites :1758
 {
 	for( int s = 0; s < P->n_sites; s++ ){
 		const rmd_site_t	&si = P->sites[ s ];
@@ -629,7 +655,8 @@ struct rmd_lean_t {
 
 // The interior [a, b] (relative to z) of helix stp ends with a proper helix whose 3' strand
 // must end at b: can any of its admissible 5' ends start it?
-RMD_FN bool rmd_tail_ok( const rmd_program_t *P, const rmd_elem_t &stp, const rmd_seq_t &sq, int z, int a, int b )
+template< class SQ >
+RMD_FN bool rmd_tail_ok( const rmd_program_t *P, const rmd_elem_t &stp, const SQ &sq, int z, int a, int b )
 {
 	const rmd_elem_t	&t = P->elems[ P->searches[ stp.tail_s ] ];
 	int	s_hi = b - t.minglen + 1;
@@ -685,8 +712,8 @@ RMD_FN int rmd_lean_begin( const rmd_program_t *P, LR &lr, rmd_lean_t &st, int s
 
 // Rebuild the element table of the current path into L and run the end-of-list
 // checks (find_ss :362-393); called only for complete structural matches.
-template< class LR, class Sink >
-RMD_FN void rmd_lean_emit( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const rmd_seq_t &sq, rmd_lane_t *L, Sink &sink )
+template< class LR, class Sink, class SQ >
+RMD_FN void rmd_lean_emit( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const SQ &sq, rmd_lane_t *L, Sink &sink )
 {
 	const int	z = st.szero;
 	for( int k = 0; k < P->n_searches; k++ ){
@@ -740,8 +767,8 @@ struct rmd_no_accel_t {
 	RMD_FN_MEMBER bool	tail( const rmd_elem_t &, int, int, int, bool * ) const { return false; }
 };
 
-template< class LR, class Sink, class Accel = rmd_no_accel_t >
-RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const rmd_seq_t &sq, int k,
+template< class LR, class Sink, class SQ, class Accel = rmd_no_accel_t >
+RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const SQ &sq, int k,
 	rmd_lane_t *L, Sink &sink, const Accel &accel = Accel() )
 {
 	const int	d = P->searches[ k ];

@@ -57,6 +57,9 @@ struct HitBuf {
 	int64_t	cap;
 	unsigned	*spill;			// [gridDim.x][spill_cap] work queue items that did not fit the LDS queue
 	int	spill_cap;
+	unsigned	*pool;			// [gridDim.x][pool_cap][3] pooled instance: items that passed the tile's tests
+	int	pool_cap, pool_min;	// ... searched once pool_min of them have come together
+	int	pool_refill;		// idle lanes of a wave that pop together
 };
 
 __device__ inline int db_code( const DbView &db, int64_t base )	// forward strand code of absolute base
@@ -474,11 +477,19 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 // dozen items, far too few for 256 lanes, and pass B is where the time goes.
 // KINDS (general instance): the element kinds it is compiled for, RMD_KIND_PK | RMD_KIND_TQ -- an
 // instance per class of descriptor, so that a pseudoknot search does not carry the 4-plex code.
-template< int BLOCK, bool LEAN, int G, int KINDS = 0 >
+// POOL (lean, G == 1): pass B does not run tile by tile.  A tile of 10 K start positions leaves some
+// hundred items that pass the first-pairs and tail tests -- 256 lanes each walk one for a few steps
+// and then wait for the slowest (14 of 64 lanes busy, measured).  The pooled instance appends the
+// survivors of every tile to a pool in the workgroup's HBM area instead and searches them once
+// pool_min have come together: a lane pops an item, rebuilds its window from the packed database
+// into a column of LDS (4 bits per base; the tile and its bit vectors are not needed then and lend
+// their place), walks it, and pops the next -- every lane busy until the pool runs dry.
+template< int BLOCK, bool LEAN, int G, int KINDS = 0, bool POOL = false >
 __global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES( KINDS ) )
 rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	static_assert( G == 1 || ( LEAN && G % ( BLOCK / 64 ) == 0 && G <= 32 ), "tile groups: lean path, whole rounds of waves" );
+	static_assert( !POOL || ( LEAN && G == 1 ), "pooled pass B: lean path, one tile per pass" );
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
 	// gP is the compact image (rmd_make_image): prog_bytes of it, a multiple of 16
@@ -487,6 +498,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const int	slot_bytes = ( tile_bytes + 15 ) & ~15;
 	__shared__ long long	s_tile;
 	__shared__ int	s_seq, s_qn, s_qhead, s_dqn, s_dqhead;
+	__shared__ int	s_pool_n, s_pool_head;
 	__shared__ int	s_ctx[ G ][ G > 1 ? 8 : 1 ];	// G > 1: seq, comp, slen, z0, p_lo, vec_words of every slot
 	const int	tid = threadIdx.x;
 	// lanes that share a tile in pass A: the workgroup, or one wave per slot
@@ -496,6 +508,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 
 	for( unsigned i = tid; i < unsigned( prog_bytes ) / 4; i += BLOCK )
 		reinterpret_cast<uint32_t *>( P )[ i ] = reinterpret_cast<const uint32_t *>( gP )[ i ];
+	if( tid == 0 ){
+		s_pool_n = 0;
+		s_pool_head = 0;
+	}
 	__syncthreads();
 
 	const int	T = db.tile_t;
@@ -590,8 +606,14 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		}
 		__syncthreads();
 		const long long	t = s_tile;
-		if( t >= n_units )
-			break;
+		bool	last = false;
+		if( t >= n_units ){
+			// (pooled: one more round, over a tile without start positions, for what the pool still holds)
+			if constexpr( POOL )
+				last = true;
+			else
+				break;
+		}
 		// what pass B needs of the tile (G > 1: of the last slot; pass B reloads per item)
 		int	seq = 0, slen = 0, z0 = 0, p_lo = 0, vec_words = 0;
 		uint8_t	*tile = tile0;
@@ -899,7 +921,137 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
 		int	k = -1;
 		bool	dry = false;
-		if constexpr( LEAN ){
+		if constexpr( POOL ){
+			// ---- pass A': every queued item takes the tail test (for every helix length its end
+			// position allows: is the pinned helix that closes the interior there?  nine in ten
+			// are not), all lanes busy; what passes goes to the pool with its entry and strand
+			unsigned	*const pool = hb.pool + size_t( blockIdx.x ) * hb.pool_cap * 3;
+			{
+				TailAccel	ac{ P, pb, tile, pb_words, p_lo, vec_words * 64, 0 };
+				for( int c = 0; c < nq; c += BLOCK ){
+					const int	i = c + tid;
+					unsigned	item = 0;
+					bool	keep = false;
+					if( i < nq ){
+						item = i < qcap ? queue[ i ] : __hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+						const int	r = int( item & 0xffffu );
+						keep = true;
+						if( tail_from_rows && r != 0xffff ){
+							const int	szero = z0 + int( item >> 16 );
+							int	hi, lo;
+							rmd_level0_range( P, szero, slen, &hi, &lo );
+							const int	span = hi - r - szero + 1;
+							keep = false;
+							for( int hl = e0.minlen; hl <= e0.maxlen && !keep; hl++ ){
+								const int	ilen = span - 2 * hl;
+								if( ilen < e0.minilen )
+									break;
+								bool	ok;
+								if( ilen <= e0.maxilen && ( !ac.tail( e0, szero, hl, span - 1 - hl, &ok ) || ok ) )
+									keep = true;
+							}
+						}
+					}
+					const unsigned long long	m = __ballot( keep );
+					if( m ){
+						int	base = 0;
+						if( lane_id == __ffsll( m ) - 1 )
+							base = atomicAdd( &s_pool_n, __popcll( m ) );
+						base = __shfl( base, __ffsll( m ) - 1 );
+						if( keep ){
+							// (at most pool_min - 1 items wait when a tile starts and a tile queues at most
+							// qtotal: the pool holds pool_min + qtotal)
+							unsigned	*e = pool + 3 * size_t( base + __popcll( m & lt_mask ) );
+							e[ 0 ] = unsigned( seq );
+							e[ 1 ] = unsigned( z0 + int( item >> 16 ) );
+							e[ 2 ] = ( item & 0xffffu ) | ( unsigned( sink.comp ) << 16 );
+						}
+					}
+				}
+			}
+			PHASE( 3 );
+			__syncthreads();
+			const int	n_pool = s_pool_n;
+			if( n_pool > 0 && ( last || n_pool >= hb.pool_min ) ){
+				// ---- pass B over the pool
+				constexpr int	NIB_MAX = 32;		// window dwords per lane the host has checked room for
+				uint32_t	*const col = reinterpret_cast<uint32_t *>( tile0 ) + tid;
+				rmd_nibseq_t<BLOCK>	nsq{ col, 0, 0 };
+				rmd_lean_t	st;
+				const rmd_no_accel_t	none;
+				for( ; ; ){
+					const unsigned long long	want = __ballot( k < 0 && !dry );
+					const unsigned long long	busy = __ballot( k >= 0 );
+					// idle lanes pop together: a window costs some hundred instructions to rebuild, and
+					// a round for one lane costs the wave as much as a round for sixteen
+					if( want && ( busy == 0 || __popcll( want ) >= hb.pool_refill ) ){
+						if( ( dbg & 32 ) && lane_id == 0 ){
+							atomicAdd( hb.ticket + 15, 1ull );
+							atomicAdd( hb.ticket + 16, ( unsigned long long )__popcll( want ) );
+						}
+						int	base = 0;
+						if( lane_id == __ffsll( want ) - 1 )
+							base = atomicAdd( &s_pool_head, __popcll( want ) );
+						base = __shfl( base, __ffsll( want ) - 1 );
+						if( k < 0 && !dry ){
+							const int	i = base + __popcll( want & lt_mask );
+							if( i < n_pool ){
+								const unsigned	*e = pool + 3 * size_t( i );
+								const int	iseq = int( __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) );
+								const int	szero = int( __hip_atomic_load( e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) );
+								const unsigned	rc = __hip_atomic_load( e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+								const int	r = int( rc & 0xffffu ), icomp = int( rc >> 16 ) & 1;
+								const int	islen = db.slen[ iseq ];
+								const int64_t	off = db.base_off[ iseq ];
+								// the window's bases [ p0, p1 ) of the strand = [ f_lo, f_hi ) of the entry as stored
+								const int	p0 = rmd_imax( szero - lm, 0 ), p1 = rmd_imin( szero + w + rm, islen );
+								const int	f_lo = icomp ? islen - p1 : p0, f_hi = icomp ? islen - p0 : p1;
+								const int64_t	g0 = ( off + f_lo ) & ~int64_t( 7 );
+								const int	n_dw = int( ( off + f_hi - g0 + 7 ) >> 3 );
+								for( int j = 0; j < n_dw && j < NIB_MAX; j++ ){
+									const int64_t	g = g0 + 8 * j;		// eight bases: half a word of codes, a byte of the mask
+									const uint32_t	cw = ( db.codes[ g >> 4 ] >> ( ( g & 8 ) * 2 ) ) & 0xffffu;
+									const uint32_t	am = ( db.amask[ g >> 5 ] >> ( g & 24 ) ) & 0xffu;
+									uint32_t	x = ( cw | ( cw << 8 ) ) & 0x00ff00ffu;
+									x = ( x | ( x << 4 ) ) & 0x0f0f0f0fu;
+									x = ( x | ( x << 2 ) ) & 0x33333333u;
+									if( icomp )
+										x ^= 0x33333333u;		// (mk_rcmp, rnamot.c:193: 3 - code)
+									uint32_t	n = ( am | ( am << 12 ) ) & 0x000f000fu;
+									n = ( n | ( n << 6 ) ) & 0x03030303u;
+									n = ( n | ( n << 3 ) ) & 0x11111111u;
+									col[ j * BLOCK ] = ( x & ~( n * 3u ) ) | ( n << 2 );	// RMA_BC_N = 4
+								}
+								nsq.flip = icomp ? -1 : 0;
+								nsq.bias = int( off - g0 ) + ( icomp ? islen : 0 );
+								sink.seq = iseq;
+								sink.comp = icomp;
+								k = rmd_lean_begin( P, lr, st, szero, islen, r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+							}else
+								dry = true;
+						}
+						continue;
+					}
+					if( busy == 0 )
+						break;
+					if( ( dbg & 32 ) && lane_id == 0 ){
+						atomicAdd( hb.ticket + 17, 1ull );
+						atomicAdd( hb.ticket + 18, ( unsigned long long )__popcll( busy ) );
+					}
+					if( k >= 0 )
+						k = rmd_lean_step( P, lr, st, nsq, k, &lane, sink, none );
+				}
+				__syncthreads();
+				if( tid == 0 ){
+					s_pool_n = 0;
+					s_pool_head = 0;
+				}
+			}
+			if( last ){
+				PHASE( 4 );
+				break;
+			}
+		}else if constexpr( LEAN ){
 
 			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
 			rmd_lean_t	st;
@@ -908,7 +1060,12 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			TailAccel	accel{ P, pb, tile, pb_words, p_lo, vec_words * 64, tail_from_rows ? 0 : -1 };
 			for( ; ; ){
 				// lanes without work pop until they hold an item that survives the tail test
+				unsigned long long	t_b0 = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
 				for( unsigned long long want; ( want = __ballot( k < 0 && !dry ) ) != 0; ){
+					if( ( dbg & 32 ) && lane_id == 0 ){
+						atomicAdd( hb.ticket + 15, 1ull );
+						atomicAdd( hb.ticket + 16, ( unsigned long long )__popcll( want ) );
+					}
 					int	base = 0;
 					if( lane_id == __ffsll( want ) - 1 )
 						base = atomicAdd( &s_qhead, __popcll( want ) );
@@ -961,10 +1118,22 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 							dry = true;
 					}
 				}
-				if( __ballot( k >= 0 ) == 0 )
+				const unsigned long long	busy = __ballot( k >= 0 );
+				unsigned long long	t_b1 = 0;
+				if( dbg & 32 ){
+					t_b1 = __builtin_amdgcn_s_memtime();
+					if( lane_id == 0 ){
+						atomicAdd( hb.ticket + 19, t_b1 - t_b0 );
+						atomicAdd( hb.ticket + 17, 1ull );
+						atomicAdd( hb.ticket + 18, ( unsigned long long )__popcll( busy ) );
+					}
+				}
+				if( busy == 0 )
 					break;
 				if( k >= 0 )
 					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink, accel );
+				if( ( dbg & 32 ) && lane_id == 0 )
+					atomicAdd( hb.ticket + 20, __builtin_amdgcn_s_memtime() - t_b1 );
 			}
 		}else{
 			GenTile	gt{ P, lean_lo, g_before, g_deep, queue, spill, qcap, nq, &s_qhead, &s_dqn, &s_dqhead,
@@ -1046,6 +1215,8 @@ struct rma_scanner {
 	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
 	unsigned	*d_spill = nullptr;		// [grid_blocks][spill_cap] queue overflow of every workgroup
 	int	spill_cap = 0;
+	unsigned	*d_pool = nullptr;		// [grid_blocks][pool_cap][3] pooled instance: items waiting for pass B
+	int	pool_cap = 0, pool_min = 1024;
 	int32_t	*h_raw = nullptr;		// pinned
 	size_t	h_raw_cap = 0;
 	std::vector<int32_t>	h_sorted;
@@ -1323,6 +1494,7 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 	( void )hipFree( sc->d_hits );
 	( void )hipFree( sc->d_counters );
 	( void )hipFree( sc->d_spill );
+	( void )hipFree( sc->d_pool );
 	for( int i = 0; i < 4; i++ )
 		if( sc->ev[ i ] )
 			( void )hipEventDestroy( sc->ev[ i ] );
@@ -1581,8 +1753,31 @@ static int scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, 
 		if( e.type == RMA_T_P5 || e.type == RMA_T_T1 || e.type == RMA_T_Q1 )
 			kinds |= RMD_KIND_TQ;
 	}
+	// the pooled lean instance (see the kernel): when the window of an item, four bits a base, fits the
+	// column a lane gets of the tile's place in LDS
+	bool	pooled = false;
+	if( lean && !grouped ){
+		const int	n_dw = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;
+		const size_t	room = size_t( ( tile_bytes + 15 ) & ~15 ) + size_t( 6 ) * ( ( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+		pooled = n_dw <= 32 && size_t( n_dw ) * BLOCK * sizeof( uint32_t ) <= room;
+		if( const char *pl = getenv( "RNAMOTIF_POOL" ) )	// "0": pass B tile by tile (tests, profiles/pool_matrix.py)
+			pooled = pooled && atoi( pl ) != 0;
+	}
+	if( pooled ){
+		if( const char *pm = getenv( "RNAMOTIF_POOL_MIN" ) )
+			sc->pool_min = std::max( 1, atoi( pm ) );
+		const int	cap = sc->pool_min + db->qcap + sc->spill_cap;
+		if( cap > sc->pool_cap ){
+			( void )hipFree( sc->d_pool );
+			sc->d_pool = nullptr;
+			sc->pool_cap = 0;
+			HIPCHK( hipMalloc( &sc->d_pool, size_t( sc->grid_blocks ) * cap * 3 * sizeof( unsigned ) ) );
+			sc->pool_cap = cap;
+		}
+	}
 	typedef void	( *kernel_t )( const rmd_program_t *, int, int, DbView, HitBuf, int, int );
-	const kernel_t	kernel = grouped ? &rma_search_kernel<BLOCK, true, SHORT_GROUP> : lean ? &rma_search_kernel<BLOCK, true, 1> :
+	const kernel_t	kernel = pooled ? &rma_search_kernel<BLOCK, true, 1, 0, true> :
+		grouped ? &rma_search_kernel<BLOCK, true, SHORT_GROUP> : lean ? &rma_search_kernel<BLOCK, true, 1> :
 		kinds == 0 ? &rma_search_kernel<BLOCK, false, 1, 0> : kinds == RMD_KIND_PK ? &rma_search_kernel<BLOCK, false, 1, RMD_KIND_PK> :
 		kinds == RMD_KIND_TQ ? &rma_search_kernel<BLOCK, false, 1, RMD_KIND_TQ> : &rma_search_kernel<BLOCK, false, 1, RMD_KIND_PK | RMD_KIND_TQ>;
 	HIPCHK( hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
@@ -1591,7 +1786,8 @@ static int scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, 
 	unsigned long long	count = 0;
 	for( int attempt = 0; attempt < 4; attempt++ ){
 		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 96 * sizeof( unsigned long long ), sc->stream ) );
-		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap };
+		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap, sc->d_pool, sc->pool_cap, sc->pool_min,
+			getenv( "RNAMOTIF_POOL_REFILL" ) ? atoi( getenv( "RNAMOTIF_POOL_REFILL" ) ) : 48 };
 		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 		hipLaunchKernelGGL( kernel, dim3( grid ), dim3( BLOCK ), lds, sc->stream,
 			sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
@@ -1614,6 +1810,10 @@ static int scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, 
 					tot += double( ph[ i ] );
 				unsigned long long	lv[ 64 ];
 				( void )hipMemcpy( lv, sc->d_counters + 16, sizeof( lv ), hipMemcpyDeviceToHost );
+				if( lean )
+					fprintf( stderr, "[dbg] pass B: %llu pop rounds of %.1f lanes, %llu steps of %.1f lanes; wave cycles popping %.1f%%, stepping %.1f%%\n",
+						lv[ 0 ], lv[ 0 ] ? double( lv[ 1 ] ) / lv[ 0 ] : 0.0, lv[ 2 ], lv[ 2 ] ? double( lv[ 3 ] ) / lv[ 2 ] : 0.0,
+						100.0 * lv[ 4 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ), 100.0 * lv[ 5 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ) );
 				for( int kk = 0; kk < dp.n_searches && kk < 32 && !lean; kk++ )
 					fprintf( stderr, "[dbg] level %2d (element %2d, type %d): %llu wave rounds, %.1f lanes each\n", kk, dp.searches[ kk ],
 						dp.elems[ dp.searches[ kk ] ].type, lv[ 2 * kk ], lv[ 2 * kk ] ? double( lv[ 2 * kk + 1 ] ) / lv[ 2 * kk ] : 0.0 );

@@ -194,6 +194,39 @@ def test_search_paths_agree(built, workdir, name, dbg):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("name", ["trna.descr", "ire.descr", "mp.ends.descr", "bulge.descr", "score.1.descr", "sprintf.descr"])
+def test_pooled_and_tile_by_tile_pass_b_agree(built, workdir, gbrna, name):
+    """Lean descriptors whose window fits a lane's column of LDS are searched by the pooled instance
+    (survivors of many tiles together, windows rebuilt from the packed database); RNAMOTIF_POOL=0 is
+    pass B tile by tile.  Same records either way -- with small pools (sessions between most tiles),
+    N-rich entries, entries shorter than the window, slices of start positions."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(31)
+    lut = np.frombuffer(b"acgtn", dtype=np.uint8)
+    seqs = [lut[rng.integers(0, 4, size=n)].tobytes() for n in (200_003, 61, 7, 40_000)]
+    seqs.append(lut[rng.choice(5, size=30_000, p=[.22, .22, .22, .22, .12])].tobytes())
+    seqs += [r[2] for r in R.read_fasta(gbrna)[:400]]
+    d = _descr(workdir, name)
+    want = oracle_scan(d, seqs)
+    sc = R.Scanner(d)
+    db = sc.database(seqs)
+    for env in ({}, {"RNAMOTIF_POOL": 0}, {"RNAMOTIF_POOL_MIN": 8, "RNAMOTIF_POOL_REFILL": 1}, {"RNAMOTIF_POOL_MIN": 100000}):
+        with _env(**env):
+            got = sc.scan(db)
+        assert got.shape == want.shape and np.array_equal(got, want), env
+    # slices of start positions (what a rank of a multi-GPU job holds)
+    sl = sc.database(seqs, ranges=[(0, 100_000), (10, 61), (0, 7), (20_000, 40_000), (5, 29_000)] + [(0, len(s)) for s in seqs[5:]])
+    ref = None
+    for env in ({"RNAMOTIF_POOL": 0}, {}):
+        with _env(**env):
+            got = sc.scan(sl)
+        if ref is None:
+            ref = got
+        assert np.array_equal(got, ref)
+    assert 0 < ref.shape[0] <= want.shape[0] or want.shape[0] == 0
+
+
 def test_tile_sizes_agree(built, workdir):
     """Tile size is a launch parameter only: 256..8192 start positions per
     workgroup give identical records."""
