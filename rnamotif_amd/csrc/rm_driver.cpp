@@ -369,10 +369,11 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		PackFile	&pk = *packs.back();
 		std::string	perr;
 		const auto	t0 = std::chrono::steady_clock::now();
-		if( !pk.load( path, perr ) )
+		// (tables and names now, the packed bases batch by batch while the batches before are searched)
+		if( !pk.open( path, perr ) )
 			fail( "%s", perr.c_str() );
 		if( getenv( "RNAMOTIF_TIMING" ) )
-			fprintf( stderr, "[timing] pack loaded: %.1f ms\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
+			fprintf( stderr, "[timing] pack opened: %.1f ms\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
 		int	first = 0;
 		while( first < pk.count() ){
 			int	count = 0;
@@ -381,6 +382,8 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 				bases += pk.slen[ first + count ];
 				count++;
 			}
+			if( !pk.ensure( first + count, perr ) )
+				fail( "%s", perr.c_str() );
 			if( pl ){
 				submit( nullptr, &pk, first, count );
 				first += count;

@@ -2,6 +2,8 @@
 #include "rm_pack.h"
 #include <cstdio>
 #include <cstring>
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace rma {
 
@@ -119,18 +121,10 @@ void PackFile::index_text()
 	}
 }
 
-template< class T >
-static bool put( FILE *fp, const std::vector<T> &v )
+template< class V >
+static bool put( FILE *fp, const V &v )
 {
-	return v.empty() || fwrite( v.data(), sizeof( T ), v.size(), fp ) == v.size();
-}
-template< class T >
-static bool get( FILE *fp, std::vector<T> &v, int64_t n )
-{
-	if( n < 0 || n > ( int64_t( 1 ) << 40 ) )
-		return false;
-	v.resize( size_t( n ) );
-	return n == 0 || fread( v.data(), sizeof( T ), size_t( n ), fp ) == size_t( n );
+	return v.empty() || fwrite( v.data(), sizeof( v[ 0 ] ), v.size(), fp ) == v.size();
 }
 
 bool PackFile::save( const std::string &path, std::string &err ) const
@@ -151,19 +145,71 @@ bool PackFile::save( const std::string &path, std::string &err ) const
 	return ok;
 }
 
-bool PackFile::load( const std::string &path, std::string &err )
+struct PackFile::Source {
+	int	fd = -1;
+	int64_t	codes_at = 0, amask_at = 0;	// file offsets of the two arrays
+	std::string	path;
+	~Source(){ if( fd >= 0 ) close( fd ); }
+};
+
+static bool pread_all( int fd, void *buf, size_t n, int64_t at )
 {
-	FILE	*fp = fopen( path.c_str(), "rb" );
-	if( fp == nullptr ){
+	char	*p = static_cast<char *>( buf );
+	while( n > 0 ){
+		const ssize_t	k = pread( fd, p, n, at );
+		if( k <= 0 )
+			return false;
+		p += k;
+		at += k;
+		n -= size_t( k );
+	}
+	return true;
+}
+
+bool PackFile::open( const std::string &path, std::string &err )
+{
+	const std::string	bad = "'" + path + "' is not a packed database of this build.";
+	std::shared_ptr<Source>	src( new Source );
+	src->path = path;
+	src->fd = ::open( path.c_str(), O_RDONLY );
+	if( src->fd < 0 ){
 		err = "can't read packed database '" + path + "'.";
 		return false;
 	}
 	char	magic[ 8 ];
 	int64_t	hdr[ 5 ];
-	bool	ok = fread( magic, 1, 8, fp ) == 8 && !memcmp( magic, PACK_MAGIC, 8 ) && fread( hdr, sizeof( hdr ), 1, fp ) == 1;
-	ok = ok && get( fp, slen, hdr[ 0 ] ) && get( fp, base_off, hdr[ 0 ] ) && get( fp, exc_off, hdr[ 0 ] ) &&
-		get( fp, codes, hdr[ 1 ] ) && get( fp, amask, hdr[ 2 ] ) && get( fp, exc, hdr[ 3 ] ) && get( fp, text, hdr[ 4 ] );
-	fclose( fp );
+	if( !pread_all( src->fd, magic, 8, 0 ) || memcmp( magic, PACK_MAGIC, 8 ) || !pread_all( src->fd, hdr, sizeof( hdr ), 8 ) ){
+		err = bad;
+		return false;
+	}
+	for( int i = 0; i < 5; i++ )
+		if( hdr[ i ] < 0 || hdr[ i ] > ( int64_t( 1 ) << 40 ) ){
+			err = bad;
+			return false;
+		}
+	const int64_t	n = hdr[ 0 ];
+	int64_t	at = 8 + int64_t( sizeof( hdr ) );
+	slen.resize( size_t( n ) );
+	base_off.resize( size_t( n ) );
+	exc_off.resize( size_t( n ) );
+	exc.resize( size_t( hdr[ 3 ] ) );
+	text.resize( size_t( hdr[ 4 ] ) );
+	bool	ok = pread_all( src->fd, slen.data(), size_t( n ) * 4, at );
+	at += n * 4;
+	ok = ok && pread_all( src->fd, base_off.data(), size_t( n ) * 8, at );
+	at += n * 8;
+	ok = ok && pread_all( src->fd, exc_off.data(), size_t( n ) * 8, at );
+	at += n * 8;
+	src->codes_at = at;
+	at += hdr[ 1 ] * 4;
+	src->amask_at = at;
+	at += hdr[ 2 ] * 4;
+	ok = ok && pread_all( src->fd, exc.data(), exc.size(), at );
+	at += hdr[ 3 ];
+	ok = ok && pread_all( src->fd, text.data(), text.size(), at );
+	codes.resize( size_t( hdr[ 1 ] ) );
+	amask.resize( size_t( hdr[ 2 ] ) );
+	codes_have_ = amask_have_ = 0;
 	if( ok ){
 		// consistency: every entry inside the arrays, text terminated
 		total_bases = 0;
@@ -184,11 +230,47 @@ bool PackFile::load( const std::string &path, std::string &err )
 		ok = ok && nul >= 2 * slen.size() && ( text.empty() || text.back() == '\0' );
 	}
 	if( !ok ){
-		err = "'" + path + "' is not a packed database of this build.";
+		err = bad;
 		return false;
 	}
 	index_text();
+	src_ = src;
 	return true;
+}
+
+bool PackFile::ensure( int n, std::string &err )
+{
+	if( !src_ )
+		return true;		// (built in memory, or read to its end)
+	const bool	all = n >= count();
+	size_t	c_to = codes.size(), m_to = amask.size();
+	if( !all && n > 0 ){
+		const int64_t	end = base_off[ n - 1 ] + ( ( int64_t( slen[ n - 1 ] ) + 31 ) / 32 ) * 32;
+		c_to = size_t( end / 16 );
+		m_to = size_t( end / 32 );
+	}else if( !all )
+		c_to = m_to = 0;
+	bool	ok = true;
+	if( c_to > codes_have_ ){
+		ok = pread_all( src_->fd, codes.data() + codes_have_, ( c_to - codes_have_ ) * 4, src_->codes_at + int64_t( codes_have_ ) * 4 );
+		codes_have_ = c_to;
+	}
+	if( ok && m_to > amask_have_ ){
+		ok = pread_all( src_->fd, amask.data() + amask_have_, ( m_to - amask_have_ ) * 4, src_->amask_at + int64_t( amask_have_ ) * 4 );
+		amask_have_ = m_to;
+	}
+	if( !ok ){
+		err = "read error on packed database '" + src_->path + "'.";
+		return false;
+	}
+	if( all )
+		src_.reset();
+	return true;
+}
+
+bool PackFile::load( const std::string &path, std::string &err )
+{
+	return open( path, err ) && ensure( count(), err );
 }
 
 bool PackFile::is_pack( const std::string &path )

@@ -17,16 +17,29 @@
 //   char     text[n_text]           sid\0sdef\0 per entry
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 #include "rm_fasta.h"
 
 namespace rma {
 
+// vector<uint32_t> whose resize( n ) does not zero what a read is about to fill (a gigabase is
+// 375 MB of words; resize( n, 0 ) still zeroes)
+template< class T >
+struct NoInitAlloc : std::allocator<T> {
+	template< class U > struct rebind { typedef NoInitAlloc<U> other; };
+	NoInitAlloc() = default;
+	template< class U > NoInitAlloc( const NoInitAlloc<U> & ) {}
+	template< class U > void construct( U *p ) { ::new( static_cast<void *>( p ) ) U; }
+	template< class U, class... A > void construct( U *p, A &&... a ) { ::new( static_cast<void *>( p ) ) U( std::forward<A>( a )... ); }
+};
+typedef std::vector<uint32_t, NoInitAlloc<uint32_t>>	PackWords;
+
 struct PackFile {
 	std::vector<int32_t>	slen;
 	std::vector<int64_t>	base_off, exc_off;
-	std::vector<uint32_t>	codes, amask;
+	PackWords	codes, amask;
 	std::vector<char>	exc, text;
 	std::vector<int64_t>	sid_off, sdef_off;	// into text (built on load)
 	int64_t	total_bases = 0;
@@ -46,9 +59,19 @@ struct PackFile {
 	void	window( int i, int comp, int lo, int hi, char *out ) const;
 	bool	save( const std::string &path, std::string &err ) const;
 	bool	load( const std::string &path, std::string &err );
+	// The same in two parts, for a reader that hands the entries on in batches: open() reads the
+	// tables, names and exceptions and checks them; ensure( n ) reads the packed bases of entries
+	// 0 .. n-1 if they are not there yet (entries lie in the file in order) -- the first batch is
+	// on its way to the GPU when a tenth of the file has been read.  codes/amask have their final
+	// size after open(): readers of earlier entries are not disturbed by ensure().
+	bool	open( const std::string &path, std::string &err );
+	bool	ensure( int n, std::string &err );
 	static bool	is_pack( const std::string &path );
 private:
 	void	index_text();
+	struct Source;
+	std::shared_ptr<Source>	src_;		// the open file while parts of it are still to be read
+	size_t	codes_have_ = 0, amask_have_ = 0;
 };
 
 }	// namespace rma

@@ -419,6 +419,21 @@ RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const
 	}
 }
 
+// The end positions a helix level walks down (find_motif :273) mostly fail at the first pair; when
+// the helix must have its 5' end paired that pair decides alone (find_motif.c:1010-1021), and the 5'
+// base is the same for every end: the partners it accepts as a 5-bit row, one code and one bit test
+// per end.  Returns the first sd' <= sd whose base pairs with the one at s5, or lo - 1.
+template< class SQ >
+RMD_FN int rmd_skip_unpaired_ends( const rmd_program_t *P, const rmd_elem_t &stp, const SQ &sq, int z, int s5, int sd, int lo )
+{
+	if( stp.minlen == 0 || !( stp.ends & RMA_5PAIRED ) )
+		return sd;
+	const unsigned	row = ( rmd_pairsets( P )[ stp.pairset ].mat2 >> ( rmd_code( sq, z + s5 ) * 5 ) ) & 31u;
+	while( sd >= lo && !( ( row >> rmd_code( sq, z + sd ) ) & 1u ) )
+		sd--;
+	return sd;
+}
+
 
 // ---------------------------------------------------------------- terminal checks
 // fm_window[] lookup (find_motif.c:1333-1385 marks): type of the element that
@@ -665,8 +680,15 @@ RMD_FN bool rmd_tail_ok( const rmd_program_t *P, const rmd_elem_t &stp, const SQ
 		s_lo = a + stp.tail_pre_min;
 	if( stp.tail_pre_max >= 0 && a + stp.tail_pre_max < s_hi )
 		s_hi = a + stp.tail_pre_max;
+	// (a helix whose 5' end must pair: the 5' bases its 3' base accepts, one bit test per start)
+	unsigned	col = 31u;
+	if( t.minlen > 0 && ( t.ends & RMA_5PAIRED ) ){
+		const unsigned	m = rmd_pairsets( P )[ t.pairset ].mat2 >> rmd_code( sq, z + b );
+		col = ( m & 1u ) | ( ( m >> 4 ) & 2u ) | ( ( m >> 8 ) & 4u ) | ( ( m >> 12 ) & 8u ) | ( ( m >> 16 ) & 16u );
+	}
 	for( int s = s_hi; s >= s_lo; s-- )
-		if( rmd_quick_wchlx( P, t, sq, z + s, z + b, rmd_s3lim( s, b, t.q_iminl, t.maxlen ) + z ) )
+		if( ( ( col >> rmd_code( sq, z + s ) ) & 1u ) &&
+			rmd_quick_wchlx( P, t, sq, z + s, z + b, rmd_s3lim( s, b, t.q_iminl, t.maxlen ) + z ) )
 			return true;
 	return false;
 }
@@ -799,9 +821,13 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 			if( k == 0 && st.lo0 > lo )
 				lo = st.lo0;
 			if( stp.quick && !( k == 0 && st.pretested ) ){
-				while( r.sd >= lo && !rmd_quick_wchlx( P, stp, sq, z + r.zero, z + r.sd,
-					rmd_s3lim( r.zero, r.sd, stp.q_iminl, stp.maxlen ) + z ) )
+				for( ; ; ){
+					r.sd = int16_t( rmd_skip_unpaired_ends( P, stp, sq, z, r.zero, r.sd, lo ) );
+					if( r.sd < lo || rmd_quick_wchlx( P, stp, sq, z + r.zero, z + r.sd,
+						rmd_s3lim( r.zero, r.sd, stp.q_iminl, stp.maxlen ) + z ) )
+						break;
 					r.sd--;
+				}
 			}
 			if( r.sd < lo )
 				return k - 1;
@@ -833,9 +859,13 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 					const rmd_elem_t	&nx = P->elems[ P->searches[ k + 1 ] ];
 					if( nx.quick ){
 						const int	nlo = nx.loop ? c.zero + nx.minglen - 1 : c.osd;
-						while( c.sd >= nlo && !rmd_quick_wchlx( P, nx, sq, z + c.zero, z + c.sd,
-							rmd_s3lim( c.zero, c.sd, nx.q_iminl, nx.maxlen ) + z ) )
+						for( ; ; ){
+							c.sd = int16_t( rmd_skip_unpaired_ends( P, nx, sq, z, c.zero, c.sd, nlo ) );
+							if( c.sd < nlo || rmd_quick_wchlx( P, nx, sq, z + c.zero, z + c.sd,
+								rmd_s3lim( c.zero, c.sd, nx.q_iminl, nx.maxlen ) + z ) )
+								break;
 							c.sd--;
+						}
 						if( c.sd < nlo )
 							continue;
 					}

@@ -972,7 +972,12 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			PHASE( 3 );
 			__syncthreads();
 			const int	n_pool = s_pool_n;
-			if( n_pool > 0 && ( last || n_pool >= hb.pool_min ) ){
+			if( n_pool > 0 && ( last || n_pool >= hb.pool_min ) && ( dbg & 2048 ) ){
+				// (diagnostic: the pool is filled and thrown away)
+				__syncthreads();
+				if( tid == 0 )
+					s_pool_n = 0;
+			}else if( n_pool > 0 && ( last || n_pool >= hb.pool_min ) ){
 				// ---- pass B over the pool
 				constexpr int	NIB_MAX = 32;		// window dwords per lane the host has checked room for
 				uint32_t	*const col = reinterpret_cast<uint32_t *>( tile0 ) + tid;
@@ -1458,6 +1463,13 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	sc->hit_cap = 1 << 17;
 	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
 	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_ctr ), 4 * sizeof( unsigned long long ), hipHostMallocDefault ) );
+	// the ordering's buffers, and one pass over whatever the hit buffer holds so that its kernels are
+	// loaded: 12 ms that would otherwise fall into the first scan
+	if( sc->dsort.reserve( sc->hit_cap, sc->dprog.hit_stride ) == hipSuccess ){
+		( void )sc->dsort.run( sc->d_hits, 4096, 10, 20, 8, sc->stream );
+		( void )hipStreamSynchronize( sc->stream );
+	}
+	( void )hipGetLastError();
 	guard.p = nullptr;
 	*out = sc;
 	return 0;
