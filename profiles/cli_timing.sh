@@ -1,18 +1,37 @@
+# profiles/cli_timing.sh [records ...] -- the whole command line program on synthetic databases of
+# the given numbers of 1 Mbase records (default 200 and 1000), from text and from a pack, with the
+# laps RNAMOTIF_TIMING prints; "search" = scanner created .. search done.
 set -e
 cd /tmp
+B=$GRAFT_REPO_ROOT/rnamotif_amd/bin
+export EFNDATA=$GRAFT_REPO_ROOT/rnamotif_amd/efndata
+D=$GRAFT_REPO_ROOT/tests/golden/descr/trna.descr
+for N in ${*:-200 1000}; do
 python3 -c "
 import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT')
 import rnamotif_amd as R
-R.write_synthetic_fasta('/tmp/syn200M.fastn', 200)
+R.write_synthetic_fasta('/tmp/syn$N.fastn', $N)
 "
-B=$GRAFT_REPO_ROOT/rnamotif_amd/bin
-$B/rnamotif_pack /tmp/syn200M.rmpk /tmp/syn200M.fastn
-export EFNDATA=$GRAFT_REPO_ROOT/rnamotif_amd/efndata
-D=$GRAFT_REPO_ROOT/tests/golden/descr/trna.descr
+$B/rnamotif_pack /tmp/syn$N.rmpk /tmp/syn$N.fastn
 for i in 1 2; do
-echo "== text"; ( time RNAMOTIF_TIMING=1 $B/rnamotif -descr $D /tmp/syn200M.fastn > /tmp/o1.txt ) 2>&1 | grep "timing\|real"
-echo "== text, 64M batches"; ( time RNAMOTIF_BATCH_BASES=64000000 RNAMOTIF_TIMING=1 $B/rnamotif -descr $D /tmp/syn200M.fastn > /tmp/o1b.txt ) 2>&1 | grep "timing\|real"
-echo "== pack"; ( time RNAMOTIF_TIMING=1 $B/rnamotif -descr $D /tmp/syn200M.rmpk > /tmp/o2.txt ) 2>&1 | grep "timing\|real"
-echo "== pack, 64M batches"; ( time RNAMOTIF_BATCH_BASES=64000000 RNAMOTIF_TIMING=1 $B/rnamotif -descr $D /tmp/syn200M.rmpk > /tmp/o2b.txt ) 2>&1 | grep "timing\|real"
+for what in fastn rmpk; do
+	echo "== $N Mbase, $what, run $i"
+	( time RNAMOTIF_BATCH_BASES=64000000 RNAMOTIF_TIMING=1 $B/rnamotif -descr $D /tmp/syn$N.$what > /tmp/o_$what.txt ) 2> /tmp/err.txt
+	grep "real\|scanner created\|search done\|pack opened" /tmp/err.txt
+	python3 - <<PY
+import re
+t = open('/tmp/err.txt').read()
+at = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r'\[timing\] ([a-z ]+?) +at +([0-9.]+) ms', t)}
+s = (at['search done'] - at['scanner created']) * 1e-3
+scans = [float(x) for x in re.findall(r'scan of \d+ entries: ([0-9.]+) ms', t)]
+reads = [float(x) for x in re.findall(r'read and packed: ([0-9.]+) ms', t)]
+reps = [float(x) for x in re.findall(r'replay of \d+ candidates: ([0-9.]+) ms', t)]
+med = lambda v: sorted(v)[len(v) // 2] if v else 0
+print('   search %.1f ms = %.2f Gbases/s; per batch (median): read+pack %.1f ms, scan %.1f ms, replay %.1f ms; %d batches' % (s * 1e3, $N * 1e-3 / s, med(reads), med(scans), med(reps), len(scans)))
+PY
 done
-md5sum /tmp/o1.txt /tmp/o1b.txt /tmp/o2.txt /tmp/o2b.txt; nproc
+done
+md5sum /tmp/o_fastn.txt /tmp/o_rmpk.txt
+rm -f /tmp/syn$N.fastn /tmp/syn$N.rmpk
+done
+nproc

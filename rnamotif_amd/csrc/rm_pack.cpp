@@ -2,6 +2,8 @@
 #include "rm_pack.h"
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <thread>
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -166,6 +168,29 @@ static bool pread_all( int fd, void *buf, size_t n, int64_t at )
 	return true;
 }
 
+// (a fresh vector is touched for the first time as it is filled: page faults and copy go at 2 GB/s
+// in one thread, so a read of more than a few MB is shared)
+static bool pread_parallel( int fd, void *buf, size_t n, int64_t at )
+{
+	const size_t	piece = size_t( 2 ) << 20;
+	unsigned	nt = unsigned( std::min<size_t>( n / piece, 8 ) );
+	nt = std::min( nt, std::max( 1u, std::thread::hardware_concurrency() ) );
+	if( nt < 2 )
+		return pread_all( fd, buf, n, at );
+	std::vector<std::thread>	pool;
+	std::vector<char>	ok( nt, 0 );
+	for( unsigned t = 0; t < nt; t++ ){
+		const size_t	lo = ( n / nt ) * t, hi = t + 1 == nt ? n : ( n / nt ) * ( t + 1 );
+		pool.emplace_back( [ =, &ok ](){ ok[ t ] = pread_all( fd, static_cast<char *>( buf ) + lo, hi - lo, at + int64_t( lo ) ); } );
+	}
+	bool	all = true;
+	for( unsigned t = 0; t < nt; t++ ){
+		pool[ t ].join();
+		all = all && ok[ t ];
+	}
+	return all;
+}
+
 bool PackFile::open( const std::string &path, std::string &err )
 {
 	const std::string	bad = "'" + path + "' is not a packed database of this build.";
@@ -252,11 +277,11 @@ bool PackFile::ensure( int n, std::string &err )
 		c_to = m_to = 0;
 	bool	ok = true;
 	if( c_to > codes_have_ ){
-		ok = pread_all( src_->fd, codes.data() + codes_have_, ( c_to - codes_have_ ) * 4, src_->codes_at + int64_t( codes_have_ ) * 4 );
+		ok = pread_parallel( src_->fd, codes.data() + codes_have_, ( c_to - codes_have_ ) * 4, src_->codes_at + int64_t( codes_have_ ) * 4 );
 		codes_have_ = c_to;
 	}
 	if( ok && m_to > amask_have_ ){
-		ok = pread_all( src_->fd, amask.data() + amask_have_, ( m_to - amask_have_ ) * 4, src_->amask_at + int64_t( amask_have_ ) * 4 );
+		ok = pread_parallel( src_->fd, amask.data() + amask_have_, ( m_to - amask_have_ ) * 4, src_->amask_at + int64_t( amask_have_ ) * 4 );
 		amask_have_ = m_to;
 	}
 	if( !ok ){
