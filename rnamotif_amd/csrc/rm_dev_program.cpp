@@ -415,6 +415,9 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		out->elems[ d ].tail_s = -1;
 		out->elems[ d ].tail_pre_min = 0;
 		out->elems[ d ].tail_pre_max = -1;
+		out->elems[ d ].head_s = -1;
+		out->elems[ d ].head_pre_min = 0;
+		out->elems[ d ].head_pre_max = 0;
 	}
 	if( out->lean_ok ){
 		// The reference walks a chain left to right and only learns at its end that the
@@ -458,6 +461,25 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 				else
 					mx += ej.maxglen;
 				t = ej.next_s;
+			}
+			// the first helix of the interior, behind single strands of bounded length only
+			{
+				long	hmn = 0, hmx = 0;
+				for( int h = d->inner_s; h >= 0; h = out->elems[ p->searches[ h ] ].next_s ){
+					const rmd_elem_t	&eh = out->elems[ p->searches[ h ] ];
+					if( eh.type == RMA_T_H5 ){
+						if( eh.quick && eh.minlen >= 1 && eh.maxglen != RMA_UNBOUNDED && hmx - hmn <= 3 && hmx < 30000 ){
+							d->head_s = int8_t( h );
+							d->head_pre_min = int16_t( hmn );
+							d->head_pre_max = int16_t( hmx );
+						}
+						break;
+					}
+					if( eh.type != RMA_T_SS || eh.maxglen == RMA_UNBOUNDED )
+						break;
+					hmn += eh.minglen;
+					hmx += eh.maxglen;
+				}
 			}
 			const rmd_elem_t	&te = out->elems[ p->searches[ t ] ];
 			if( t != d->inner_s && te.quick && te.type == RMA_T_H5 && !te.loop && te.minlen >= 1 && mn < 30000 ){

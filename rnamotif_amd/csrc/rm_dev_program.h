@@ -79,7 +79,9 @@ struct rmd_elem_t {
 					// this fixed length: its last pin_end_n bases, once the window end is known
 	int8_t	back_s;			// head of a level: the level to go back to when this one is exhausted -- the
 					// nearest one below it that has more than one alternative (-1: the item is done)
-	int8_t	pad2_[ 1 ];
+	int8_t	head_s;			// helix: level of the first proper helix of its interior when only ss of bounded
+					// total length lie before it (its 5' start is pinned to the interior's start), else -1
+	int16_t	head_pre_min, head_pre_max;	// ... that total length
 };
 
 // First-tuple masks of a triplex / 4-plex pair table: match_triplex()/match_4plex() give up at

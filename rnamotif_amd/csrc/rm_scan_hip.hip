@@ -565,6 +565,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			( te.ends & RMA_5PAIRED ) && ( te.ends & RMA_3PAIRED ) && te.maxglen != RMA_UNBOUNDED;
 	}
 
+	// the same for the first helix of the first element's interior (pooled instance)
+	const bool	head_from_rows = POOL && bitpar && e0.head_s >= 0 && !( dbg & 4096 ) &&
+		P->elems[ P->searches[ e0.head_s >= 0 ? e0.head_s : 0 ] ].rows == 0;
+
 	// a slot belongs to one wave when G > 1: its phases are ordered within the wave (LDS
 	// executes a wave's accesses in order), the waves need not march in step
 #define SLOT_SYNC()	do{ \
@@ -936,7 +940,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						item = i < qcap ? queue[ i ] : __hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 						const int	r = int( item & 0xffffu );
 						keep = true;
-						if( tail_from_rows && r != 0xffff ){
+						if( ( tail_from_rows || head_from_rows ) && r != 0xffff ){
 							const int	szero = z0 + int( item >> 16 );
 							int	hi, lo;
 							rmd_level0_range( P, szero, slen, &hi, &lo );
@@ -946,9 +950,32 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 								const int	ilen = span - 2 * hl;
 								if( ilen < e0.minilen )
 									break;
-								bool	ok;
-								if( ilen <= e0.maxilen && ( !ac.tail( e0, szero, hl, span - 1 - hl, &ok ) || ok ) )
-									keep = true;
+								if( ilen > e0.maxilen )
+									continue;
+								bool	ok = true, t;
+								if( tail_from_rows && ac.tail( e0, szero, hl, span - 1 - hl, &t ) )
+									ok = t;
+								if( ok && head_from_rows ){
+									// the first helix of the interior, 5' strand at one of a few offsets from the
+									// interior's start: can any 3' end start it? (rows_win: its first minlen pairs)
+									const rmd_elem_t	&H = P->elems[ P->searches[ e0.head_s ] ];
+									const int	lim = ( H.ends & RMA_5PAIRED ) ? H.mplim : ( H.mplim > 1 ? H.mplim : 1 );
+									const int	b = szero + span - 1 - hl;		// last position of the interior
+									ok = false;
+									for( int pre = e0.head_pre_min; pre <= e0.head_pre_max && !ok; pre++ ){
+										const int	s5 = szero + hl + pre;
+										const int	top = rmd_imin( s5 + H.maxglen - 1, b ), bot = s5 + H.minglen - 1;
+										if( top < bot )
+											continue;
+										const int	w0 = top - 63, q_hi = w0 - p_lo + 64;
+										// (undecided -- a range wider than a word, bits the vectors do not hold: kept)
+										if( top - bot >= 64 || q_hi - H.minlen < 0 || q_hi + 96 > vec_words * 64 )
+											ok = true;
+										else
+											ok = rows_win( pb, pb_words, tile, p_lo, H.minlen, lim, ( H.ends & RMA_5PAIRED ) != 0, s5, w0, bot ) != 0;
+									}
+								}
+								keep = ok;
 							}
 						}
 					}
