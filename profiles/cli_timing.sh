@@ -24,10 +24,11 @@ t = open('/tmp/err.txt').read()
 at = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r'\[timing\] ([a-z ]+?) +at +([0-9.]+) ms', t)}
 s = (at['search done'] - at['scanner created']) * 1e-3
 scans = [float(x) for x in re.findall(r'scan of \d+ entries: ([0-9.]+) ms', t)]
-reads = [float(x) for x in re.findall(r'read and packed: ([0-9.]+) ms', t)]
+reads = [float(x) for x in re.findall(r'read (?:and packed|from the pack): ([0-9.]+) ms', t)]
 reps = [float(x) for x in re.findall(r'replay of \d+ candidates: ([0-9.]+) ms', t)]
 med = lambda v: sorted(v)[len(v) // 2] if v else 0
-print('   search %.1f ms = %.2f Gbases/s; per batch (median): read+pack %.1f ms, scan %.1f ms, replay %.1f ms; %d batches' % (s * 1e3, $N * 1e-3 / s, med(reads), med(scans), med(reps), len(scans)))
+print('   scans', ' '.join('%.0f' % x for x in scans)); print('   reads', ' '.join('%.0f' % x for x in reads)); print('   replays', ' '.join('%.0f' % x for x in reps))
+print('   search %.1f ms = %.2f Gbases/s; per batch (median): read(+pack) %.1f ms, scan %.1f ms, replay %.1f ms; %d batches' % (s * 1e3, $N * 1e-3 / s, med(reads), med(scans), med(reps), len(scans)))
 PY
 done
 done

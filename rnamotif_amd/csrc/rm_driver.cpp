@@ -144,6 +144,13 @@ void Replayer::replay_packed( const PackFile &pk, int first, const int32_t *hits
 // being printed.  rnamot.c:158-185 is one loop; its three parts are all that it has.
 namespace {
 
+// (laps of RNAMOTIF_TIMING: milliseconds since the first one)
+double lap_clock()
+{
+	static const auto	t0 = std::chrono::steady_clock::now();
+	return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
+}
+
 struct Batch {
 	std::unique_ptr<PackFile>	own;	// (a slice of a packed database on disk has no copy of its own)
 	const PackFile	*pk = nullptr;
@@ -227,8 +234,8 @@ private:
 			}
 			b.hits.assign( hits, hits + b.n_hits * rma_hit_stride( &prog_ ) );	// (the scanner's buffer is its next scan's)
 			if( timing_ )
-				fprintf( stderr, "[timing] scan of %d entries: %.1f ms, %lld candidates\n", b.count,
-					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), ( long long )b.n_hits );
+				fprintf( stderr, "[timing] scan of %d entries: %.1f ms, %lld candidates (done at +%.1f)\n", b.count,
+					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), ( long long )b.n_hits, lap_clock() );
 			std::unique_lock<std::mutex>	lk( mu_ );
 			cv_.wait( lk, [ & ]{ return to_out_.size() < 2 || closing_; } );
 			to_out_.push_back( std::move( b ) );
@@ -256,8 +263,8 @@ private:
 				continue;
 			}
 			if( timing_ )
-				fprintf( stderr, "[timing] replay of %lld candidates: %.1f ms\n", ( long long )b.n_hits,
-					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
+				fprintf( stderr, "[timing] replay of %lld candidates: %.1f ms (done at +%.1f)\n", ( long long )b.n_hits,
+					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), lap_clock() );
 			std::lock_guard<std::mutex>	lk( mu_ );
 			if( in_flight_ > 0 )
 				in_flight_--;
@@ -292,6 +299,7 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 	int64_t batch_bases, SearchStats *stats )
 {
 	SearchStats	st;
+	( void )lap_clock();		// (origin of the laps)
 	Replayer	rp( d, prog, out );
 	rp.begin();
 	bool	use_stdin = d.args.dbfnames.empty();
@@ -382,8 +390,12 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 				bases += pk.slen[ first + count ];
 				count++;
 			}
+			const auto	t1 = std::chrono::steady_clock::now();
 			if( !pk.ensure( first + count, perr ) )
 				fail( "%s", perr.c_str() );
+			if( getenv( "RNAMOTIF_TIMING" ) )
+				fprintf( stderr, "[timing] batch of %d entries read from the pack: %.1f ms (done at +%.1f)\n", count,
+					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t1 ).count(), lap_clock() );
 			if( pl ){
 				submit( nullptr, &pk, first, count );
 				first += count;
@@ -476,11 +488,20 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 	flush();
 	if( pl ){
 		pl->drain();
+		if( getenv( "RNAMOTIF_TIMING" ) )
+			fprintf( stderr, "[timing] pipeline drained at +%.1f\n", lap_clock() );
 		pl.reset();
+		if( getenv( "RNAMOTIF_TIMING" ) )
+			fprintf( stderr, "[timing] pipeline threads joined at +%.1f\n", lap_clock() );
 	}
 	rp.end();
 	if( stats )
 		*stats = st;
+	// The packed databases are left to the end of the process (the command line program leaves with
+	// _exit() after its last line, rm_main.cpp): returning a gigabase of touched pages to the system
+	// page by page took 55 ms of a 160 ms search, for memory the exit hands back wholesale.
+	for( std::unique_ptr<PackFile> &pk : packs )
+		( void )pk.release();
 	return 0;
 }
 

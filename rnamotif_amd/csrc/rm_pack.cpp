@@ -172,8 +172,8 @@ static bool pread_all( int fd, void *buf, size_t n, int64_t at )
 // in one thread, so a read of more than a few MB is shared)
 static bool pread_parallel( int fd, void *buf, size_t n, int64_t at )
 {
-	const size_t	piece = size_t( 2 ) << 20;
-	unsigned	nt = unsigned( std::min<size_t>( n / piece, 8 ) );
+	const size_t	piece = size_t( 1 ) << 20;
+	unsigned	nt = unsigned( std::min<size_t>( n / piece, 16 ) );
 	nt = std::min( nt, std::max( 1u, std::thread::hardware_concurrency() ) );
 	if( nt < 2 )
 		return pread_all( fd, buf, n, at );

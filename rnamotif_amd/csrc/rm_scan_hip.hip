@@ -1499,6 +1499,24 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	( void )hipGetLastError();
 	guard.p = nullptr;
 	*out = sc;
+	// One scan of eight start positions, so that what the runtime sets up on first use (code objects of
+	// the kernel instance this descriptor takes, the first device allocations of a database) belongs to
+	// the creation of the scanner and not to the first batch of a search: 15-50 ms there.  All 'a':
+	// nothing pairs, whatever the descriptor, so no helix is ever walked.
+	if( !getenv( "RNAMOTIF_NO_WARMUP" ) && sc->prog.dminlen <= 2000 ){
+		const std::string	warm( size_t( std::max( sc->prog.dminlen, 1 ) + 7 ), 'a' );
+		const char	*seqs[ 1 ] = { warm.c_str() };
+		const int32_t	lens[ 1 ] = { int32_t( warm.size() ) };
+		rma_db_t	*wdb = nullptr;
+		char	werr[ 256 ];
+		if( rma_db_create( sc, seqs, lens, 1, &wdb, werr, sizeof( werr ) ) == 0 ){
+			const int32_t	*wh = nullptr;
+			int64_t	wn = 0;
+			( void )rma_scan( sc, wdb, &wh, &wn, werr, sizeof( werr ) );	// (efn2 tables not set yet: refused, harmless)
+			rma_db_destroy( wdb );
+		}
+		( void )hipGetLastError();
+	}
 	return 0;
 }
 
