@@ -196,6 +196,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
+    # the scanner's own warm-up scan (eight start positions at creation) off: the untimed --warmup steps
+    # below do that job here, and a rocprofv3 summary of this command then holds whole launches only
+    os.environ.setdefault("RNAMOTIF_NO_WARMUP", "1")
     descr_files = args.descr.split(",")
     descrs = [R.Descriptor(["-descr", f]) for f in descr_files]
     descr = descrs[0]
