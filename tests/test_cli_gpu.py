@@ -147,7 +147,8 @@ def test_pack_and_text_mixed(built, workdir, gbrna, tmp_path):
 
 def test_whole_program_throughput(built, workdir, tmp_path):
     """`rnamotif -descr trna.descr syn.fastn` from text and from a pack, 200 Mbase here (the 1 Gbase
-    figures are in DESIGN.md section 6): identical output, and a floor on the search -- reading or
+    figures -- 10.9 Gbases/s from a pack, 7.9 from text -- are in DESIGN.md section 6 and profiles/r02_cli_timing.txt):
+    identical output, and a floor on the search -- reading or
     loading, packing, upload, scan, copy back, score program and printing, i.e. the program without
     process start, HIP initialisation (0.1-0.25 s on the test boxes, not ours to shorten) and exit --
     that a one-thread reader does not reach."""
@@ -174,5 +175,5 @@ def test_whole_program_throughput(built, workdir, tmp_path):
     print("\n200 Mbase:", {k: "search %.3f s = %.2f Gbases/s, whole program %.2f s" % (v[0], 0.2 / v[0], v[1]) for k, v in res.items()})
     assert len({v[2] for v in res.values()}) == 1 and res["text"][3] > 10000
     assert 0.2 / res["text"][0] >= 1.5, res
-    assert 0.2 / res["pack"][0] >= 1.5, res
+    assert 0.2 / res["pack"][0] >= 3.0, res          # (30-33 ms measured: read batch by batch while the batches before are searched)
     assert res["text"][0] < res["text, one thread"][0]
