@@ -11,7 +11,7 @@ os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
 names = sys.argv[1:] or ["trna.descr"]
 HERE = os.getcwd()
 seqs = R.synthetic_records(100)
-os.chdir(os.path.join(ROOT, "tests", "golden", "descr"))
+os.chdir(os.path.join(ROOT, "tests", "golden", "test"))
 for name in names:
     d = R.Descriptor(["-descr", name])
     sc = R.Scanner(d)

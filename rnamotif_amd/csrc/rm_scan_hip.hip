@@ -814,8 +814,46 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					if( __ballot( any ) == 0 )
 						continue;		// (nothing to queue for these 64 positions)
 					if( split_ranks ){
+						// Lanes whose end range is one word: "rank r leaves the 3' strand the ends
+						// hi-r-q_smaxl .. hi-r-q_sminl" (find_pknot3 :566-568) = some bit of W0 among
+						// 63-r-(q_smaxl-q_sminl) .. 63-r = bit 63-r of W0 smeared upwards over that many
+						// places; the ranks to queue are the bits of one word, taken one per round -- a few
+						// rounds instead of one per rank of the window.
+						unsigned long long	Rm = 0;
+						if( any && one_word ){
+							unsigned long long	D = W0;
+							for( int have = 1, need = e0.q_smaxl - e0.q_sminl + 1; have < need; ){
+								const int	st = rmd_imin( have, need - have );
+								D |= D << st;
+								have += st;
+							}
+							const int	rmax = rmd_imin( rmd_imin( n_rank - 1, hi - lo ), 63 );
+							Rm = rmax >= 0 ? D & ( ~0ull << ( 63 - rmax ) ) : 0ull;
+						}
+						while( __ballot( Rm != 0 ) ){
+							bool	pred = Rm != 0;
+							const int	i = pred ? 63 - __builtin_clzll( Rm ) : 0;
+							const int	r = 63 - i;
+							if( pred )
+								Rm &= ~( 1ull << i );
+							if( pred && P->lit_ehi >= 0 ){
+								const int	e_ = hi - r;
+								const int	a_ = rmd_imax( szero + P->lit_lo, e_ - P->lit_ehi );
+								const int	b_ = rmd_imin( szero + lit_hi, e_ - P->lit_elo );
+								if( a_ > b_ )
+									pred = false;
+								else
+									LIT_IN( a_, b_, pred );
+							}
+							if( __ballot( pred ) == 0 )
+								continue;
+							QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+						}
+						// (end ranges wider than a word: rank by rank)
+						const bool	slow = any && !one_word;
+						if( __ballot( slow ) )
 						for( int r = 0; r < n_rank; r++ ){
-							bool	pred = any && r <= hi - lo;
+							bool	pred = slow && r <= hi - lo;
 							if( pred && one_word ){
 								// this rank's end leaves the 3' strand the ends hi-r-q_smaxl .. hi-r-q_sminl
 								// (find_pknot3 :566-568): bits 63-r-(q_smaxl-q_sminl) .. 63-r of W0
