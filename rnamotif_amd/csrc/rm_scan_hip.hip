@@ -786,99 +786,137 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			auto	win = [ & ]( int szero, int top, int r0, int lo ) -> unsigned long long {
 				return rows_win( pb, pb_words, tile, p_lo, hl0, lim, ends5, szero, top - r0 - 63, lo );
 			};
+			int	n_wait = 0;		// pseudoknot pre-filter: start positions of this wave that wait in cbuf
 			for( int j = 0; j < n_pos; j += UNIT ){
-				const int	rel = j + utid;
+				const int	rel0 = j + utid;
+				bool	valid0 = rel0 < T && z0 + rel0 <= slen - P->dminlen && z0 + rel0 < pos_hi;
+				if( valid0 )
+					LIT_OK( z0 + rel0, valid0 );
+				if constexpr( !LEAN ){
+				if( pk0 ){
+					// The literal and the anchored prefix of the first helix leave one start position in
+					// sixteen (pk1.descr: "^tg", "gaaa"): the row windows below would run for four lanes of
+					// a wave.  Survivors are collected, per wave, and taken 64 at a time.
+					__shared__ uint16_t	s_cbuf[ BLOCK / 64 ][ 128 ];
+					uint16_t	*const cbuf = s_cbuf[ tid >> 6 ];
+					valid0 = valid0 && rmd_prefix_ok( P, e0, sq, z0 + rel0 );
+					const unsigned long long	mv = __ballot( valid0 );
+					if( valid0 )
+						cbuf[ n_wait + __popcll( mv & lt_mask ) ] = uint16_t( rel0 );
+					n_wait += __popcll( mv );
+					const bool	last_j = j + UNIT >= n_pos;
+					while( n_wait >= 64 || ( last_j && n_wait > 0 ) ){
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+						__builtin_amdgcn_wave_barrier();
+						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+						const int	n_take = n_wait < 64 ? n_wait : 64;
+						const bool	valid = lane_id < n_take;
+						const int	rel = valid ? int( cbuf[ lane_id ] ) : 0;
+						const int	rest = n_wait - n_take;
+						const int	moved = lane_id < rest ? int( cbuf[ n_take + lane_id ] ) : 0;
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+						__builtin_amdgcn_wave_barrier();
+						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+						if( lane_id < rest )
+							cbuf[ lane_id ] = uint16_t( moved );
+						n_wait = rest;
+						const int	szero = z0 + rel;
+						int	hi = 0, lo = 1;
+						if( valid )
+							rmd_level0_range( P, szero, slen, &hi, &lo );
+						do{
+							// first helix of a pseudoknot (find_pknot5/find_pknot3 :495-640): its 3' end
+							// lies between s5 + 2*minlen + interior - 1 and the window end minus what must
+							// follow it; search the position only if some end there can start the helix
+							bool	any = false;
+							unsigned long long	W0 = 0;		// 3' ends top-63 .. top that can, when the whole range is one word
+							const int	top = hi - e0.q_sminl, bot = szero + 2 * e0.minlen + e0.q_iminl - 1;
+							const bool	one_word = top - bot < 64 && e0.q_smaxl >= 0;
+							if( valid ){
+								if( one_word ){
+									W0 = top >= bot ? win( szero, top, 0, bot ) : 0;
+									any = W0 != 0;
+								}else
+									for( int r0 = 0; !any && r0 <= top - bot; r0 += 64 )
+										any = win( szero, top, r0, bot ) != 0;
+							}
+							if( __ballot( any ) == 0 )
+								continue;		// (nothing to queue for these 64 positions)
+							if( split_ranks ){
+								// Lanes whose end range is one word: "rank r leaves the 3' strand the ends
+								// hi-r-q_smaxl .. hi-r-q_sminl" (find_pknot3 :566-568) = some bit of W0 among
+								// 63-r-(q_smaxl-q_sminl) .. 63-r = bit 63-r of W0 smeared upwards over that many
+								// places; the ranks to queue are the bits of one word, taken one per round -- a few
+								// rounds instead of one per rank of the window.
+								unsigned long long	Rm = 0;
+								if( any && one_word ){
+									unsigned long long	D = W0;
+									for( int have = 1, need = e0.q_smaxl - e0.q_sminl + 1; have < need; ){
+										const int	st = rmd_imin( have, need - have );
+										D |= D << st;
+										have += st;
+									}
+									const int	rmax = rmd_imin( rmd_imin( n_rank - 1, hi - lo ), 63 );
+									Rm = rmax >= 0 ? D & ( ~0ull << ( 63 - rmax ) ) : 0ull;
+								}
+								while( __ballot( Rm != 0 ) ){
+									bool	pred = Rm != 0;
+									const int	i = pred ? 63 - __builtin_clzll( Rm ) : 0;
+									const int	r = 63 - i;
+									if( pred )
+										Rm &= ~( 1ull << i );
+									if( pred && P->lit_ehi >= 0 ){
+										const int	e_ = hi - r;
+										const int	a_ = rmd_imax( szero + P->lit_lo, e_ - P->lit_ehi );
+										const int	b_ = rmd_imin( szero + lit_hi, e_ - P->lit_elo );
+										if( a_ > b_ )
+											pred = false;
+										else
+											LIT_IN( a_, b_, pred );
+									}
+									if( __ballot( pred ) == 0 )
+										continue;
+									QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+								}
+								// (end ranges wider than a word: rank by rank)
+								const bool	slow = any && !one_word;
+								if( __ballot( slow ) )
+								for( int r = 0; r < n_rank; r++ ){
+									bool	pred = slow && r <= hi - lo;
+									if( pred && one_word ){
+										// this rank's end leaves the 3' strand the ends hi-r-q_smaxl .. hi-r-q_sminl
+										// (find_pknot3 :566-568): bits 63-r-(q_smaxl-q_sminl) .. 63-r of W0
+										const int	i_hi = 63 - r, i_lo = rmd_imax( i_hi - ( e0.q_smaxl - e0.q_sminl ), 0 );
+										pred = i_hi >= 0 && ( ( W0 >> i_lo ) & ( i_hi - i_lo >= 63 ? ~0ull : ( 2ull << ( i_hi - i_lo ) ) - 1 ) ) != 0;
+									}
+									if( pred && P->lit_ehi >= 0 ){
+										// the rank fixes the end of the knot: the literal must also sit at
+										// an admissible distance from that end
+										const int	e_ = hi - r;
+										const int	a_ = rmd_imax( szero + P->lit_lo, e_ - P->lit_ehi );
+										const int	b_ = rmd_imin( szero + lit_hi, e_ - P->lit_elo );
+										if( a_ > b_ )
+											pred = false;
+										else
+											LIT_IN( a_, b_, pred );
+									}
+									if( __ballot( pred ) == 0 )
+										continue;
+									QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+								}
+							}else
+								QPUSH( any, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
+						}while( 0 );
+					}
+					continue;
+				}
+				}
+				const int	rel = rel0;
 				const int	szero = z0 + rel;
-				bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
-				if( valid )
-					LIT_OK( szero, valid );
+				const bool	valid = valid0;
 				int	hi = 0, lo = 1;
 				if( valid )
 					rmd_level0_range( P, szero, slen, &hi, &lo );
-				if( pk0 ){
-					// first helix of a pseudoknot (find_pknot5/find_pknot3 :495-640): its 3' end
-					// lies between s5 + 2*minlen + interior - 1 and the window end minus what must
-					// follow it; search the position only if some end there can start the helix
-					bool	any = false;
-					unsigned long long	W0 = 0;		// 3' ends top-63 .. top that can, when the whole range is one word
-					const int	top = hi - e0.q_sminl, bot = szero + 2 * e0.minlen + e0.q_iminl - 1;
-					const bool	one_word = top - bot < 64 && e0.q_smaxl >= 0;
-					if( valid && rmd_prefix_ok( P, e0, sq, szero ) ){
-						if( one_word ){
-							W0 = top >= bot ? win( szero, top, 0, bot ) : 0;
-							any = W0 != 0;
-						}else
-							for( int r0 = 0; !any && r0 <= top - bot; r0 += 64 )
-								any = win( szero, top, r0, bot ) != 0;
-					}
-					if( __ballot( any ) == 0 )
-						continue;		// (nothing to queue for these 64 positions)
-					if( split_ranks ){
-						// Lanes whose end range is one word: "rank r leaves the 3' strand the ends
-						// hi-r-q_smaxl .. hi-r-q_sminl" (find_pknot3 :566-568) = some bit of W0 among
-						// 63-r-(q_smaxl-q_sminl) .. 63-r = bit 63-r of W0 smeared upwards over that many
-						// places; the ranks to queue are the bits of one word, taken one per round -- a few
-						// rounds instead of one per rank of the window.
-						unsigned long long	Rm = 0;
-						if( any && one_word ){
-							unsigned long long	D = W0;
-							for( int have = 1, need = e0.q_smaxl - e0.q_sminl + 1; have < need; ){
-								const int	st = rmd_imin( have, need - have );
-								D |= D << st;
-								have += st;
-							}
-							const int	rmax = rmd_imin( rmd_imin( n_rank - 1, hi - lo ), 63 );
-							Rm = rmax >= 0 ? D & ( ~0ull << ( 63 - rmax ) ) : 0ull;
-						}
-						while( __ballot( Rm != 0 ) ){
-							bool	pred = Rm != 0;
-							const int	i = pred ? 63 - __builtin_clzll( Rm ) : 0;
-							const int	r = 63 - i;
-							if( pred )
-								Rm &= ~( 1ull << i );
-							if( pred && P->lit_ehi >= 0 ){
-								const int	e_ = hi - r;
-								const int	a_ = rmd_imax( szero + P->lit_lo, e_ - P->lit_ehi );
-								const int	b_ = rmd_imin( szero + lit_hi, e_ - P->lit_elo );
-								if( a_ > b_ )
-									pred = false;
-								else
-									LIT_IN( a_, b_, pred );
-							}
-							if( __ballot( pred ) == 0 )
-								continue;
-							QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
-						}
-						// (end ranges wider than a word: rank by rank)
-						const bool	slow = any && !one_word;
-						if( __ballot( slow ) )
-						for( int r = 0; r < n_rank; r++ ){
-							bool	pred = slow && r <= hi - lo;
-							if( pred && one_word ){
-								// this rank's end leaves the 3' strand the ends hi-r-q_smaxl .. hi-r-q_sminl
-								// (find_pknot3 :566-568): bits 63-r-(q_smaxl-q_sminl) .. 63-r of W0
-								const int	i_hi = 63 - r, i_lo = rmd_imax( i_hi - ( e0.q_smaxl - e0.q_sminl ), 0 );
-								pred = i_hi >= 0 && ( ( W0 >> i_lo ) & ( i_hi - i_lo >= 63 ? ~0ull : ( 2ull << ( i_hi - i_lo ) ) - 1 ) ) != 0;
-							}
-							if( pred && P->lit_ehi >= 0 ){
-								// the rank fixes the end of the knot: the literal must also sit at
-								// an admissible distance from that end
-								const int	e_ = hi - r;
-								const int	a_ = rmd_imax( szero + P->lit_lo, e_ - P->lit_ehi );
-								const int	b_ = rmd_imin( szero + lit_hi, e_ - P->lit_elo );
-								if( a_ > b_ )
-									pred = false;
-								else
-									LIT_IN( a_, b_, pred );
-							}
-							if( __ballot( pred ) == 0 )
-								continue;
-							QPUSH( pred, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
-						}
-					}else
-						QPUSH( any, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
-					continue;
-				}
 				for( int r0 = 0; r0 < n_rank; r0 += 64 ){
 					unsigned long long	W = 0;
 					if( valid && r0 <= hi - lo )
@@ -1507,7 +1545,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 				kinds |= RMD_KIND_TQ;
 		}
 		for( int wg = GENERAL_WAVES( kinds ); wg >= 1 && !found; wg-- ){
-			const size_t	budget = ( 160 * 1024 ) / wg - 1024;	// (static __shared__ and allocation granules)
+			const size_t	budget = ( 160 * 1024 ) / wg - 2560;	// (static __shared__ -- 1 KB of it the pre-filter's wave buffers -- and allocation granules)
 			for( int t = 8192; t >= ( wg > 1 ? 3072 : 1024 ); t -= 256 )
 				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, false, sc->qcap ) <= budget ){
 					sc->tile_t = t;
