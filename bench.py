@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the scan path (BASELINE.json).
 
-One step = one pass of the hot path over one synthetic database that is already resident in
-HBM: search kernel over every start position of both strands, efn kernel over every candidate,
-copy back and ordering of the hit records (rma_scan of the C ABI).  Workload at N=1: descr/
-trna.descr (4-stem cloverleaf, bits()+efn() score) over the 100 Mbase synthetic FASTA of
-BASELINE.md (100 records x 1 Mbase, iid uniform acgt, numpy default_rng(20240601)) -- BASELINE
-config 2.  `value` is that, over exactly --steps steps.
+One step = SURVEY.md section 8d's step: one pass of the hot path over one batch of synthetic
+database -- upload of the packed batch (0.375 B/base, from page-locked host memory, on the device's
+upload stream), search kernel over every start position of both strands, efn kernel over every
+candidate, ordering and copy back of the hit records.  The upload of step i+1 runs under the
+kernels of step i (two buffers in HBM, rma_db_create_packed_async + rma_scan of the C ABI), as in
+the command line program's pipeline; every step's bases cross PCIe inside the timed region.
+
+Workload at N=1: descr/trna.descr (4-stem cloverleaf, bits()+efn() score) over the 100 Mbase
+synthetic FASTA of BASELINE.md (100 records x 1 Mbase, iid uniform acgt, numpy default_rng(20240601))
+-- BASELINE config 2.  `value` is that, over exactly --steps steps, upload included.
 
 Next to it, on rank 0 at N=1 with the default workload (none of it inside the timed K steps):
-  sustained        the same step repeated for at least a second
-  h2d_inclusive    SURVEY.md section 8d's step: upload of the packed database (0.375 B/base from host
-                   memory), scan, copy back of the hits -- per step; never `value`
+  resident         the same scan over a database that stays in HBM (no upload in the step)
+  sustained        the headline step repeated for at least a second
   north_star_1gbase  the north star's own size: trna.descr over 1 Gbase on one GPU, >= 1 s timed
+  cli_end_to_end   the whole command line program (bin/rnamotif -descr trna.descr) over 1 Gbase from a
+                   text file and from a packed database: search time and whole-process time
   roofline         HBM roofline of the search kernel from HIP events taken here; its two passes
-                   apart (pre-filter alone with RNAMOTIF_DBG=1); HBM traffic and the VALU-issue
+                   apart (pre-filter alone, option dbg=1); HBM traffic and the VALU-issue
                    secondary roofline from the committed rocprofv3 PMC summary -- only if that
                    summary was made from the kernel sources this run uses (hash), else null
   cpu_baseline     the scalar oracle on a bounded sample, one core (and all host cores)
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank scans its own
---records Mbase of the same synthetic stream (records [records*rank, records*rank+records)), i.e.
-weak scaling; with --total-records R the R records are divided among the ranks (strong scaling:
-BASELINE config 4 is --total-records 1000, config 5 adds --descr qu+tr.descr,mp.ends.descr).  The
-hit records are gathered to rank 0 over RCCL inside the timed region, the path's only exchange.
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the default is BASELINE
+config 4: 1000 records (1 Gbase) divided among the ranks, strong scaling; --weak gives every rank
+its own --records Mbase instead.  --descr qu+tr.descr,mp.ends.descr is config 5 (both descriptors
+over one upload of the shard, their kernels side by side on two streams).  The hit records travel
+to rank 0 inside the timed region -- the path's only exchange: rma_gather_hits() of the C ABI
+(RCCL all-gather of the counts + grouped send/receive, device to device), or, if that cannot be
+set up, the same over torch.distributed.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,7 +38,9 @@ import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,8 +52,10 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 once two or more
 # waves share the SIMD: 256 CUs x 4 SIMDs x 2.4 GHz / 2
 VALU_PEAK_NOMINAL = 256 * 4 * 2.4e9 / 2 / 1e9
-KERNEL_SOURCES = ("rm_scan_hip.hip", "rm_scan_core.h", "rm_dev_program.h", "rm_dev_program.cpp", "rm_efn_core.h")
-PROFILE = os.path.join(ROOT, "profiles", "r02_trna")     # _pmc_summary.csv, _meta.json (profiles/collect.sh + summarize.py)
+KERNEL_SOURCES = ("rm_scan_kernel.h", "rm_scan_core.h", "rm_dev_program.h", "rm_dev_program.cpp", "rm_efn_core.h", "rm_kernels.h")
+PROFILE_ROUND = "r03"
+PROFILE = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_trna")     # _pmc_summary.csv, _meta.json (profiles/collect.sh + summarize.py)
+SEED = 20240601
 
 
 def kernel_hash():
@@ -56,14 +67,23 @@ def kernel_hash():
 
 
 def synthetic_slice(first: int, count: int, length: int):
-    """Records [first, first+count) of the synthetic stream (seed 20240601)."""
+    """Records [first, first+count) of the synthetic stream (numpy default_rng(20240601), record k =
+    the k-th draw of `length` integers).  A record of even length takes length/2 steps of the PCG64
+    stream (two 32-bit draws per step), so a rank jumps to its first record instead of generating
+    everything before it."""
     import numpy as np
-    rng = np.random.default_rng(20240601)
     lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    bg = np.random.PCG64(SEED)
+    rng = np.random.Generator(bg)
+    skip = 0
+    if length % 2 == 0:
+        bg.advance(first * (length // 2))
+    else:
+        skip = first
     out = []
-    for k in range(first + count):
+    for k in range(skip + count):
         v = rng.integers(0, 4, size=length)
-        if k >= first:
+        if k >= skip:
             out.append(lut[v].tobytes())
     return out
 
@@ -142,24 +162,91 @@ def cpu_baseline_all_cores(descr_path, seqs, bases_per_core):
                       f"{sum(r[1] for r in res)} candidates, slowest process {busy:.1f} s (wall {wall:.1f} s with start-up)"}
 
 
+def cli_end_to_end(descr_path, seqs, tmp, threads_env=None):
+    """The whole command line program over `seqs` written as a FASTA text file and as a packed
+    database: per input the best of two runs -- `search` = from the scanner's creation to the last
+    line printed (reading or loading, packing, upload, kernels, score program, printing; the laps
+    RNAMOTIF_TIMING prints), `process` = the whole program by this process's clock (HIP start-up,
+    descriptor compilation and exit included)."""
+    import numpy as np
+    import rnamotif_amd as R
+    fa, pk = os.path.join(tmp, "syn.fastn"), os.path.join(tmp, "syn.rmpk")
+    with open(fa, "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(b">syn%04d synthetic uniform ACGT seed=%d len=%d\n" % (i, SEED, len(s)))
+            a = np.frombuffer(s, dtype=np.uint8)
+            full = (len(a) // 50) * 50
+            f.write(np.concatenate([a[:full].reshape(-1, 50), np.full((full // 50, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+            if full < len(a):
+                f.write(a[full:].tobytes() + b"\n")
+    R.Pack.write(pk, [(b"syn%04d" % i, b"synthetic uniform ACGT seed=%d len=%d" % (SEED, len(s)), s) for i, s in enumerate(seqs)])
+    bases = sum(len(s) for s in seqs)
+    env = dict(os.environ, RNAMOTIF_TIMING="1", EFNDATA=R.EFNDATA_DIR)
+    env.pop("RNAMOTIF_NO_WARMUP", None)
+    out = {"bases": bases, "command": "rnamotif_amd/bin/rnamotif -descr " + os.path.basename(descr_path) + " <file>",
+           "what": "search = scanner created .. last line printed; process = the whole program, HIP start-up included; best of two runs"}
+    ref_stdout = None
+    for what, path in (("text", fa), ("pack", pk)):
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            p = subprocess.run([R.CLI_PATH, "-descr", descr_path, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.perf_counter() - t0
+            if p.returncode != 0:
+                out[what] = {"error": p.stderr.decode("utf-8", "replace")[-300:]}
+                best = None
+                break
+            laps = {}
+            for line in p.stderr.decode("utf-8", "replace").splitlines():
+                if line.startswith("[timing]") and " at " in line and line.rstrip().endswith("ms"):
+                    name, at = line[len("[timing]"):].rsplit(" at ", 1)
+                    laps[name.strip()] = float(at.split()[0])
+            search_ms = laps.get("search done", float("nan")) - laps.get("scanner created", float("nan"))
+            hits = p.stdout.count(b"\n>")
+            if ref_stdout is None:
+                ref_stdout = hashlib.md5(p.stdout).hexdigest()
+            same = hashlib.md5(p.stdout).hexdigest() == ref_stdout
+            cur = {"search_ms": round(search_ms, 1), "search_mbases_per_s": round(bases / search_ms / 1e3, 1),
+                   "process_ms": round(wall * 1e3, 1), "process_mbases_per_s": round(bases / wall / 1e6, 1),
+                   "hits_printed": hits, "stdout_identical_to_first_run": same}
+            if best is None or cur["search_ms"] < best["search_ms"]:
+                best = cur
+        if best is not None:
+            out[what] = best
+    for f in (fa, pk):
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--records", type=int, default=100, help="1 Mbase records per GPU (default 100 = 100 Mbase)")
-    ap.add_argument("--total-records", type=int, default=0, help="strong scaling: this many records divided among the ranks")
+    ap.add_argument("--records", type=int, default=100, help="1 Mbase records per GPU (default 100 = 100 Mbase; with --gpus N > 1 only under --weak)")
+    ap.add_argument("--total-records", type=int, default=0,
+                    help="strong scaling: this many records divided among the ranks (default with --gpus N > 1: 1000 = BASELINE config 4)")
+    ap.add_argument("--weak", action="store_true", help="with --gpus N > 1: every rank scans its own --records records")
     ap.add_argument("--record-len", type=int, default=1_000_000)
     ap.add_argument("--descr", default=os.path.join(ROOT, "tests", "golden", "descr", "trna.descr"),
                     help="descriptor file; a comma separated list = mixed batch (every descriptor over the same database)")
     ap.add_argument("--cpu-bases", type=int, default=12_000_000, help="sample size of the CPU baseline (0 = skip it and the other extras)")
-    ap.add_argument("--north-star-records", type=int, default=1000, help="records of the 1-GPU north star run (0 = skip)")
+    ap.add_argument("--north-star-records", type=int, default=1000, help="records of the 1-GPU north star run and of the command line leg (0 = skip)")
+    ap.add_argument("--resident", action="store_true", help="no upload inside the step: the database stays in HBM (then `value` is the resident rate)")
+    ap.add_argument("--gather", choices=("native", "torch"), default="native", help="N > 1: rma_gather_hits (RCCL behind the C ABI) or torch.distributed")
+    ap.add_argument("--backend", default=os.environ.get("RNAMOTIF_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo: tests with several ranks on one GPU)")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank_env = int(os.environ.get("RANK", "0"))
+    if world_env > 1 and args.total_records == 0 and not args.weak:
+        args.total_records = 1000           # BASELINE config 4 / 5: 1 Gbase divided among the ranks
     default_workload = (args.descr == ap.get_default("descr") and args.records == 100 and
-                        args.record_len == 1_000_000 and args.total_records == 0)
+                        args.record_len == 1_000_000 and args.total_records == 0 and not args.resident)
     extras = world_env == 1 and args.cpu_bases > 0 and "," not in args.descr
     strong = args.total_records > 0
     if strong:
@@ -183,47 +270,94 @@ def main():
 
     world, rank = world_env, rank_env
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # (tests run several ranks on one GPU: RNAMOTIF_DEVICE names it)
+    dev_index = int(os.environ.get("RNAMOTIF_DEVICE", local_rank))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the scan path has no CPU implementation")
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(minutes=10))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the scan path has no CPU implementation")
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
+        else:
+            dist.init_process_group(backend=args.backend, timeout=datetime.timedelta(minutes=10))
+    coll_dev = dev if (world > 1 and args.backend == "nccl") else torch.device("cpu")
 
     os.environ.setdefault("EFNDATA", R.EFNDATA_DIR)
-    # the scanner's own warm-up scan (eight start positions at creation) off: the untimed --warmup steps
-    # below do that job here, and a rocprofv3 summary of this command then holds whole launches only
-    os.environ.setdefault("RNAMOTIF_NO_WARMUP", "1")
     descr_files = args.descr.split(",")
     descrs = [R.Descriptor(["-descr", f]) for f in descr_files]
     descr = descrs[0]
     seqs = seqs_all[:n_rec] if seqs_all is not None else synthetic_slice(first_rec, n_rec, args.record_len)
-    scs = [R.Scanner(d, device=local_rank) for d in descrs]
-    dbs = [s.database(seqs) for s in scs]
-    sc, db = scs[0], dbs[0]
+    scs = [R.Scanner(d, device=dev_index) for d in descrs]
+    sc = scs[0]
+    tmpdir = tempfile.mkdtemp(prefix="rnamotif_bench_")
+    # the rank's share as a packed database in page-locked host memory: what a step uploads
+    pkpath = os.path.join(tmpdir, "shard%d.rmpk" % rank)
+    R.Pack.write(pkpath, [(b"syn%04d" % (first_rec + i), b"", s) for i, s in enumerate(seqs)])
+    pack = R.Pack(pkpath)
+    os.unlink(pkpath)
+    pack.pin()
 
-    from rnamotif_amd.distributed import gather_hits as gather_to_rank0
+    from rnamotif_amd.distributed import gather_hits as torch_gather, NativeGather
     my_index = [first_rec + i for i in range(n_rec)]   # entry numbers within the whole job
+    native = None
+    gather_kind = "none (1 rank)"
+    if world > 1:
+        gather_kind = "torch.distributed " + args.backend
+        if args.gather == "native" and args.backend == "nccl":
+            try:
+                native = NativeGather(rank, world, dev_index, coll_dev)
+                gather_kind = "rma_gather_hits (RCCL all-gather of counts + grouped send/recv, device to device)"
+            except Exception as e:      # noqa: BLE001 -- the same exchange over torch.distributed then
+                sys.stderr.write(f"bench.py (rank {rank}): native gather not available ({e}); using torch.distributed\n")
+                native = None
+        # every rank must take the same path
+        from rnamotif_amd.distributed import all_ok
+        if not all_ok(native is not None, coll_dev):
+            native = None
+            if args.gather == "native" and args.backend == "nccl":
+                gather_kind = "torch.distributed " + args.backend + " (native gather refused on some rank)"
 
-    def gather_hits(h, stride):
-        """Variable length gather of hit records to rank 0 over RCCL (rnamotif_amd/distributed.py,
-        the same function the world-size-2 gloo tests run)."""
-        if world == 1:
-            return [h]
-        # every rank holds a consecutive run of entries: the per-rank arrays in rank order are the
-        # ordered hit stream of the whole job, left as they arrive (no concatenation on rank 0)
-        return gather_to_rank0(h, my_index, stride, device=dev, concat=False)
+    def new_db(wait):
+        return sc.database_from_pack(pack, wait=wait)
 
-    def step(scs_=scs, dbs_=dbs):
+    def scan_all(db):
+        """Every descriptor over db, kernels side by side; the records of all of them on rank 0."""
+        for s_ in scs:
+            s_.scan_begin(db)
         n = 0
-        for d_, sc_, db_ in zip(descrs, scs_, dbs_):
-            n += sum(part.shape[0] for part in gather_hits(sc_.scan(db_, copy=False), d_.hit_stride))
+        for d_, s_ in zip(descrs, scs):
+            if world == 1:
+                n += s_.scan_end(copy=False).shape[0]
+            elif native is not None:
+                s_.scan_end_on_device()
+                h, _ = native.gather(s_, my_index)
+                n += h.shape[0]
+            else:
+                # every rank holds a consecutive run of entries: the per-rank arrays in rank order are the
+                # ordered hit stream of the whole job, left as they arrive (no concatenation on rank 0)
+                n += sum(part.shape[0] for part in torch_gather(s_.scan_end(copy=False), my_index, d_.hit_stride,
+                                                                device=coll_dev, concat=False))
         return n
+
+    state = {"cur": new_db(True)}
+
+    def step_h2d():
+        """Upload of the next batch under the scan of this one; this one's block of HBM back to the pool."""
+        nxt = new_db(False)
+        n = scan_all(state["cur"])
+        state["cur"].close()
+        state["cur"] = nxt
+        return n
+
+    def step_resident():
+        return scan_all(state["cur"])
+
+    step = step_resident if args.resident else step_h2d
 
     for _ in range(args.warmup):
         step()
@@ -238,13 +372,15 @@ def main():
     total_hits = 0
     for _ in range(args.steps):
         total_hits = step()
+    state["cur"].wait()                 # (the upload the last step started is part of it)
     fence()
     dt = time.perf_counter() - t0
+    db = state["cur"]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tb = torch.tensor([db.bases], dtype=torch.int64, device=dev)
+        tb = torch.tensor([db.bases], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         job_bases = int(tb.item())
     else:
@@ -255,8 +391,8 @@ def main():
         s_tot, e_tot = [], []
         for _ in range(reps):
             tot = [0.0, 0.0]
-            for sc_, db_ in zip(scs, dbs):
-                _, s_ms, e_ms = sc_.scan_device(db_)
+            for sc_ in scs:
+                _, s_ms, e_ms = sc_.scan_device(db)
                 tot[0] += s_ms
                 tot[1] += e_ms
             s_tot.append(tot[0])
@@ -267,9 +403,19 @@ def main():
     pass_a_ms = None
     if rank == 0 and world == 1 and args.cpu_bases > 0:       # (not under the profiler: profiles/collect.sh passes --cpu-bases 0,
         # so that every launch of the kernel it counts is a whole one)
-        os.environ["RNAMOTIF_DBG"] = "1"
-        pass_a_ms, _ = kernel_ms(3)
-        os.environ.pop("RNAMOTIF_DBG")
+        for s_ in scs:
+            s_.set_option("dbg", 1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(2)
+        os.dup2(devnull, 2)             # (the diagnostic lines of dbg launches are not this run's output)
+        try:
+            pass_a_ms, _ = kernel_ms(3)
+        finally:
+            os.dup2(saved, 2)
+            os.close(devnull)
+            os.close(saved)
+        for s_ in scs:
+            s_.set_option("dbg", 0)
 
     out = None
     if rank == 0:
@@ -296,11 +442,13 @@ def main():
                          "unit": "G wave64-instr/s", "frac": round(ach / VALU_PEAK_NOMINAL, 4),
                          "peak_measured": measured_peak,
                          "frac_of_measured": round(ach / measured_peak, 4) if measured_peak else None,
-                         "formula": "SQ_INSTS_VALU per launch (profiles/r02_trna_pmc_summary.csv) / kernel_ms of this run; "
+                         "formula": f"SQ_INSTS_VALU per launch (profiles/{PROFILE_ROUND}_trna_pmc_summary.csv) / kernel_ms of this run; "
                                     "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; peak_measured = profiles/valu_peak.hip at 4 waves per SIMD",
                          "salu_per_valu": round(counters.get("SQ_INSTS_SALU", 0) / counters["SQ_INSTS_VALU"], 3)}
             if "SQ_THREAD_CYCLES_VALU" in counters and "SQ_ACTIVE_INST_VALU" in counters:
                 secondary["active_lanes_of_64"] = round(counters["SQ_THREAD_CYCLES_VALU"] / counters["SQ_ACTIVE_INST_VALU"], 1)
+        where = ("database resident in HBM (no upload in the step)" if args.resident else
+                 "every step uploads its batch (0.375 B/base from page-locked host memory, upload stream) under the kernels of the step before")
         out = {
             "metric": "Mbases scanned/sec (whole node) + hits/sec, " + names,
             "value": round(value, 3),
@@ -319,11 +467,12 @@ def main():
                 "workload": f"{names} ({'mixed batch, ' if len(descrs) > 1 else ''}{'+'.join(str(d.n_elems) for d in descrs)} elements) over "
                             + (f"{args.total_records} x {args.record_len} base synthetic records divided among the ranks" if strong else
                                f"{args.records} x {args.record_len} base synthetic records per GPU")
-                            + " (iid uniform acgt, numpy default_rng(20240601)), both strands; database resident in HBM",
+                            + f" (iid uniform acgt, numpy default_rng({SEED})), both strands; " + where,
+                "step": "SURVEY.md 8d: H2D of the packed batch + search + efn + ordering + D2H of the hits" if not args.resident else "resident scan",
                 "bases_per_gpu": bases_per_gpu,
                 "total_bases": total_bases,
                 "candidates": total_hits,
-                "parallelism": f"{world} rank(s), sequences sharded, RCCL gather of hit records" if world > 1 else "1 GPU",
+                "parallelism": f"{world} rank(s), sequences sharded, gather of hit records: {gather_kind}" if world > 1 else "1 GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -334,7 +483,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 8),
                 "traffic": traffic,
                 "traffic_note": "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes over this workload "
-                                "(profiles/r02_trna_pmc_summary.csv); null when that summary was made from other kernel sources",
+                                f"(profiles/{PROFILE_ROUND}_trna_pmc_summary.csv); null when that summary was made from other kernel sources",
                 "algorithmic_bytes": int(algo_bytes),
                 "algorithmic_bytes_per_base": ALGO_BYTES_PER_BASE,
                 "kernel_ms": round(search_ms, 3),
@@ -350,45 +499,33 @@ def main():
         }
 
     if rank == 0 and extras:
-        # ---- the same step for at least a second
-        n_sus, t0 = 0, time.perf_counter()
-        while True:
-            step()
-            n_sus += 1
-            if time.perf_counter() - t0 >= 1.2:
-                break
-        torch.cuda.synchronize()
-        ds = time.perf_counter() - t0
-        out["sustained"] = {"steps": n_sus, "seconds": round(ds, 3), "value": round(db.bases * n_sus / ds / 1e6, 3), "unit": "Mbases/s"}
-
-        # ---- SURVEY 8d's step: upload of the packed database + scan + copy back of the hits
-        import tempfile
-        with tempfile.TemporaryDirectory() as tmp:
-            pkpath = os.path.join(tmp, "syn.rmpk")
-            R.Pack.write(pkpath, [(b"syn%04d" % i, b"", s) for i, s in enumerate(seqs)])
-            pack = R.Pack(pkpath)
-            for _ in range(2):
-                d2 = sc.database_from_pack(pack)
-                sc.scan(d2, copy=False)
-                d2.close()
-            n_h2d, t0 = 0, time.perf_counter()
-            while n_h2d < 10 or time.perf_counter() - t0 < 0.5:
-                d2 = sc.database_from_pack(pack)
-                sc.scan(d2, copy=False)
-                d2.close()
-                n_h2d += 1
+        def timed(fn, min_steps, min_s):
+            fn()
+            n, t0 = 0, time.perf_counter()
+            while n < min_steps or time.perf_counter() - t0 < min_s:
+                fn()
+                n += 1
+            state["cur"].wait()
             torch.cuda.synchronize()
-            dh = time.perf_counter() - t0
-            pack.close()
-        out["h2d_inclusive"] = {"value": round(db.bases * n_h2d / dh / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dh / n_h2d * 1e3, 3),
-                                "steps": n_h2d,
-                                "what": "per step: device allocation, upload of the packed database from pageable host memory "
-                                        "(0.375 B/base), search + efn kernels, copy back and ordering of the hits, free; not `value`"}
+            return n, time.perf_counter() - t0
 
-        # ---- the north star's own size on one GPU
+        # ---- the headline step for at least a second
+        n_sus, ds = timed(step, 1, 1.2)
+        out["sustained"] = {"steps": n_sus, "seconds": round(ds, 3), "value": round(db.bases * n_sus / ds / 1e6, 3), "unit": "Mbases/s"}
+        # ---- the two kinds of step side by side: upload inside and database resident
+        n_h, dh = timed(step_h2d, 20, 0.5)
+        n_r, dr = timed(step_resident, 20, 0.5)
+        out["h2d_inclusive"] = {"value": round(db.bases * n_h / dh / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dh / n_h * 1e3, 3), "steps": n_h,
+                                "what": "SURVEY.md 8d's step (= `value`'s): upload of the packed batch under the kernels of the step before, search + efn "
+                                        "kernels, ordering, copy back of the hits"}
+        out["resident"] = {"value": round(db.bases * n_r / dr / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dr / n_r * 1e3, 3), "steps": n_r,
+                           "what": "the same scan over a database that stays in HBM"}
+        out["h2d_over_resident"] = round(out["h2d_inclusive"]["value"] / out["resident"]["value"], 3)
+
+        # ---- the north star's own size on one GPU, and the whole command line over it
         if default_workload and args.north_star_records > n_rec and seqs_all is not None and len(seqs_all) >= args.north_star_records:
             big = seqs_all[: args.north_star_records]
-            db.close()
+            state["cur"].close()
             bdb = sc.database(big)
             for _ in range(2):
                 sc.scan(bdb, copy=False)
@@ -404,6 +541,11 @@ def main():
                                         "candidates": hits_big, "kernel_ms": round(big_ms, 3), "efn_kernel_ms": round(big_efn, 3),
                                         "what": "descr/trna.descr over 1000 x 1 Mbase synthetic records on one GPU, database resident in HBM"}
             bdb.close()
+            state["cur"] = new_db(True)
+            try:
+                out["cli_end_to_end"] = cli_end_to_end(args.descr, big, tmpdir)
+            except Exception as e:      # noqa: BLE001 -- a leg of its own: the headline stands without it
+                out["cli_end_to_end"] = {"error": str(e)[:300]}
         out["cpu_baseline"] = cpu_baseline(descr, seqs, args.cpu_bases)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         out["cpu_baseline_all_cores"] = cpu_all
@@ -411,6 +553,13 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
+    state["cur"].close()
+    try:
+        os.rmdir(tmpdir)
+    except OSError:
+        pass
+    if native is not None:
+        native.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -60,12 +60,23 @@ int	rma_scanner_create( const rma_program_t *prog, const rma_efndata_t *efn, int
 		rma_scanner_t **out, char *err, size_t errlen );
 /* tables for the program's efn2() sites (RM_getefn2data, efn2.c:130); copied to the device */
 int	rma_scanner_set_efn2data( rma_scanner_t *sc, const rma_efn2data_t *efn2, char *err, size_t errlen );
+/* Launch-shape and diagnostic switches (DESIGN.md has the table).  The RNAMOTIF_* environment is read
+ * once, by rma_scanner_create(); the switches that may change between scans change through this call
+ * only: "dbg", "pool", "pool_min", "pool_refill", "host_sort", "timing", "short". */
+int	rma_scanner_set_option( rma_scanner_t *sc, const char *name, int value, char *err, size_t errlen );
+/* One scan of eight start positions, thrown away: what the runtime sets up on first use (code objects,
+ * the first allocations, the ordering's kernels) is paid here and not in the first batch of a search.
+ * The command line program calls it once the scanner is complete; the library never does by itself. */
+int	rma_scanner_warmup( rma_scanner_t *sc, char *err, size_t errlen );
 void	rma_scanner_destroy( rma_scanner_t *sc );
 
 /* ---- database: n sequences of lower case letters as the reference's readers
  * deliver them (dbutil.c: every alpha character kept, u -> t).  They are packed
  * 2 bits + 1 ambiguity bit per base and uploaded; the host text is not kept.  A database
- * belongs to the scanner it was created for (its tiles are laid out for that descriptor). */
+ * lives on the device of the scanner named at its creation (sc may be NULL: device 0) and holds
+ * nothing that depends on a descriptor: every scanner of that device can scan it, side by side if
+ * they like (rma_db_attach, rma_scan_begin) -- one upload, many descriptors.  Device memory of a
+ * destroyed database is kept for the next one of about its size (no allocation per batch). */
 int	rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
 		rma_db_t **out, char *err, size_t errlen );
 /* The same, answering only for start positions pos_lo[i] <= szero < pos_hi[i] of each strand
@@ -77,6 +88,12 @@ int	rma_db_create_ranges( rma_scanner_t *sc, const char *const *seqs, const int3
 		rma_db_t **out, char *err, size_t errlen );
 void	rma_db_destroy( rma_db_t *db );
 int64_t	rma_db_bases( const rma_db_t *db );
+/* Lay db out for scanner sc (the tiling of its entries for that descriptor's tile size) ahead of sc's
+ * first scan of it, which would otherwise do it.  A database may be attached to any number of scanners
+ * of its device. */
+int	rma_db_attach( rma_scanner_t *sc, rma_db_t *db, char *err, size_t errlen );
+/* wait until the upload of db is complete (rma_db_create_packed_async) */
+int	rma_db_wait( rma_db_t *db, char *err, size_t errlen );
 
 /* ---- packed database on disk (no counterpart in the reference, which re-reads the text
  * on every run, rnamot.c:157-183): the readers' output -- names, definition lines and
@@ -98,6 +115,14 @@ int	rma_pack_seq( const rma_pack_t *pk, int32_t i, char *buf );
 /* entries [first, first+count) straight into HBM; hit records count entries from first */
 int	rma_db_create_packed( rma_scanner_t *sc, const rma_pack_t *pk, int32_t first, int32_t count,
 		rma_db_t **out, char *err, size_t errlen );
+/* The same without waiting for the copies: they run on the device's upload stream, under whatever the
+ * scanners' streams are doing; a scan of the database waits for them on the device.  The pack must
+ * stay as it is until rma_db_wait() or the end of a scan of the database.  From page-locked memory
+ * (rma_pack_pin) the call returns at once; from pageable memory the runtime stages the words first. */
+int	rma_db_create_packed_async( rma_scanner_t *sc, const rma_pack_t *pk, int32_t first, int32_t count,
+		rma_db_t **out, char *err, size_t errlen );
+/* page-lock the packed words of pk so that uploads from it are plain DMA (undone by rma_pack_close) */
+int	rma_pack_pin( rma_pack_t *pk, char *err, size_t errlen );
 /* The same database in memory, read from sequence files the way rnamotif reads them (DB_fnext,
  * dbutil.c:12-40; fmt "fastn" | "pir" | "gb" or NULL; maxslen = rnamotif's -N, 0 for its default):
  * FASTA files through the parallel reader, everything else -- and every entry a reader has a
@@ -119,6 +144,17 @@ int	rma_db_create_packed_ranges( rma_scanner_t *sc, const rma_pack_t *pk, const 
 int	rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **hits, int64_t *n_hits,
 		char *err, size_t errlen );
 
+/* rma_scan() in two halves.  rma_scan_begin() puts the search kernel on the scanner's stream and
+ * returns; rma_scan_end() waits for it, runs the energy kernel and the ordering, copies the records
+ * back and returns them as rma_scan() does.  Between the two the host is free: to begin the scan of
+ * another scanner (two descriptors over one database run side by side), or to upload the next
+ * database (rma_db_create_packed_async).  One scan in flight per scanner. */
+int	rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err, size_t errlen );
+int	rma_scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, char *err, size_t errlen );
+/* rma_scan_end() that leaves the ordered records in HBM (*d_hits is a device pointer, valid until
+ * the scanner's next scan): for rma_gather_hits(), which sends them from there. */
+int	rma_scan_end_on_device( rma_scanner_t *sc, const int32_t **d_hits, int64_t *n_hits, char *err, size_t errlen );
+
 /* The device part of rma_scan() alone (search kernel + efn kernel, no copy back,
  * no sort), for measurement: returns the candidate count and the time of the
  * search kernel as measured with HIP events on the scanner's stream. */
@@ -131,6 +167,29 @@ int	rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, flo
  * out[n][stride] must not overlap hits.  Host only -- what rank 0 of mrnamotif does with the
  * MT_RESULT messages it receives (mrnamotif.c:733-760). */
 int	rma_sort_hits( const int32_t *hits, int64_t n_hits, int32_t stride, int32_t *out, char *err, size_t errlen );
+
+/* ---- the one exchange of a multi-GPU search: the records of every rank's last scan to one rank,
+ * over RCCL (xGMI), device to device -- mrnamotif's MT_RESULT messages, mrnamotif.c:733-760 and
+ * :898-917.  One process per GPU.  Rank 0 makes an id (rma_comm_unique_id) and hands it to the
+ * others by whatever the job has (MPI_Bcast, a torch.distributed broadcast, a file); every rank then
+ * calls rma_comm_create() -- collectively.  RCCL is loaded at run time (librccl.so.1); a world of
+ * one rank needs none. */
+#define RMA_COMM_ID_BYTES	128
+typedef struct rma_comm	rma_comm_t;
+int	rma_comm_unique_id( uint8_t id[ RMA_COMM_ID_BYTES ], char *err, size_t errlen );
+int	rma_comm_create( const uint8_t id[ RMA_COMM_ID_BYTES ], int rank, int world, int device,
+		rma_comm_t **out, char *err, size_t errlen );
+void	rma_comm_destroy( rma_comm_t *comm );
+/* Collective.  Every rank has ended a scan of its shard with rma_scan_end_on_device() (or rma_scan_end:
+ * the records are still in HBM).  global_index[ i ], i < n_index, is the number in the whole database
+ * of entry i of this rank's shard: word 0 of the records is rewritten to it on the device.  An
+ * all-gather of the counts (8 bytes per rank), then one grouped send/receive: on rank `root`,
+ * *hits / *n_hits are all records, rank by rank, each rank's part in the reference's order (when the
+ * ranks hold consecutive runs of entries that is the whole job's order; otherwise rma_sort_hits()
+ * merges); elsewhere *n_hits = 0.  counts, if not NULL, receives every rank's count on every rank.
+ * The memory belongs to the communicator and is valid until its next gather. */
+int	rma_gather_hits( rma_comm_t *comm, rma_scanner_t *sc, const int32_t *global_index, int32_t n_index, int root,
+		const int32_t **hits, int64_t *n_hits, int64_t *counts, char *err, size_t errlen );
 
 /* ---- replay: run the score program over candidates and print accepted hits
  * in the reference's format to a stdio stream opened on path ("-" = stdout). */

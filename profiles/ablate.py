@@ -44,7 +44,7 @@ def main():
         for name, dbg in (("all", None), ("pass_a_only", "1")):
             if dbg is not None and args.quick:
                 continue
-            os.environ["RNAMOTIF_DBG"] = str(int(dbg or 0) | args.dbg_or)
+            sc.set_option("dbg", int(dbg or 0) | args.dbg_or)
             sc.scan_device(db)
             ms = []
             for _ in range(args.reps):
@@ -55,10 +55,10 @@ def main():
                 out["candidates"] = n
                 out["efn_ms"] = round(e_ms, 3)
         if not args.quick:
-            os.environ["RNAMOTIF_DBG"] = str(34 | args.dbg_or)     # 2: count queued items, 32: wave cycles per phase
+            sc.set_option("dbg", 34 | args.dbg_or)     # 2: count queued items, 32: wave cycles per phase
             sys.stderr.flush()
             sc.scan_device(db)      # prints "[dbg] queued items" on stderr
-        os.environ.pop("RNAMOTIF_DBG", None)
+        sc.set_option("dbg", 0)
         out["dbg_or"] = args.dbg_or
         out["gbases_per_s"] = round(db.bases / out["all_ms"] / 1e6, 2)
         print(json.dumps(out), flush=True)

@@ -18,9 +18,9 @@ for name in names:
     db = sc.database(seqs)
     sc.scan_device(db)
     print("==", name, "search %.3f ms" % sc.scan_device(db)[1], flush=True)
-    os.environ["RNAMOTIF_DBG"] = "34"
+    sc.set_option("dbg", 34)
     sc.scan_device(db)
     sys.stderr.flush()
-    del os.environ["RNAMOTIF_DBG"]
+    sc.set_option("dbg", 0)
     db.close()
     sc.close()

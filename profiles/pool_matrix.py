@@ -28,11 +28,10 @@ for path in names:
     db = sc.database(seqs)
     res = []
     for pool in ("0", "1"):
-        os.environ["RNAMOTIF_POOL"] = pool
+        sc.set_option("pool", int(pool))
         sc.scan_device(db)
         n, ms, _ = min((sc.scan_device(db) for _ in range(3)), key=lambda x: x[1])
         res.append((n, ms))
-    del os.environ["RNAMOTIF_POOL"]
     print("%-22s %9d candidates  tile by tile %8.3f ms  pooled %8.3f ms  %+5.1f%%" % (name, res[0][0], res[0][1], res[1][1], 100 * (res[1][1] / res[0][1] - 1)), flush=True)
     assert res[0][0] == res[1][0]
     db.close()

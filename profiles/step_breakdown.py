@@ -30,7 +30,7 @@ for _ in range(20):
     sc.scan_device(db)
     t.append(time.perf_counter() - t0)
 print("device part (rma_scan_device): median %.3f ms" % (np.median(t) * 1e3))
-os.environ["RNAMOTIF_TIMING"] = "1"
+sc.set_option("timing", 1)
 sys.stderr.flush()
 for _ in range(3):
     sc.scan(db, copy=False)

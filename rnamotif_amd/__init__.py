@@ -65,6 +65,19 @@ def lib() -> C.CDLL:
     L.rma_program_info.restype = None
     L.rma_scanner_create.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_scanner_destroy.argtypes = [vp]
+    L.rma_scanner_set_option.argtypes = [vp, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.rma_scanner_warmup.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.rma_db_attach.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
+    L.rma_db_wait.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.rma_db_create_packed_async.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_pack_pin.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.rma_scan_begin.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
+    L.rma_scan_end.argtypes = [vp, C.POINTER(i32p), i64p, C.c_char_p, C.c_size_t]
+    L.rma_scan_end_on_device.argtypes = [vp, C.POINTER(vp), i64p, C.c_char_p, C.c_size_t]
+    L.rma_comm_unique_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.rma_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_comm_destroy.argtypes = [vp]
+    L.rma_gather_hits.argtypes = [vp, vp, i32p, C.c_int32, C.c_int, C.POINTER(i32p), i64p, i64p, C.c_char_p, C.c_size_t]
     L.rma_db_create.argtypes = [vp, cpp, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_db_destroy.argtypes = [vp]
     L.rma_db_create_ranges.argtypes = [vp, cpp, i32p, i32p, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -162,7 +175,7 @@ class Database:
 
     def __init__(self, scanner: "Scanner", seqs: Optional[Sequence[bytes]] = None, pack: Optional["Pack"] = None,
                  first: int = 0, count: Optional[int] = None, ranges: Optional[Sequence[Tuple[int, int]]] = None,
-                 entries: Optional[Sequence[int]] = None):
+                 entries: Optional[Sequence[int]] = None, wait: bool = True):
         L = lib()
         self.scanner = scanner
         h = C.c_void_p()
@@ -180,7 +193,12 @@ class Database:
             # entries [first, first+count) of a packed database, uploaded as they are
             count = pack.count - first if count is None else count
             self.n_seqs = count
-            _check(L.rma_db_create_packed(scanner._h, pack._h, first, count, C.byref(h), err, _ERRLEN), err)
+            if wait:
+                _check(L.rma_db_create_packed(scanner._h, pack._h, first, count, C.byref(h), err, _ERRLEN), err)
+            else:
+                # the copies run on the device's upload stream; the pack stays as it is until a scan has ended
+                self._pack = pack
+                _check(L.rma_db_create_packed_async(scanner._h, pack._h, first, count, C.byref(h), err, _ERRLEN), err)
         else:
             self.n_seqs = len(seqs)
             arr = _cstr_array(seqs)
@@ -194,6 +212,11 @@ class Database:
                 _check(L.rma_db_create(scanner._h, arr, lens, len(seqs), C.byref(h), err, _ERRLEN), err)
         self._h = h
         self.bases = L.rma_db_bases(h)
+
+    def wait(self) -> None:
+        """Until the upload is complete (wait=False databases)."""
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_db_wait(self._h, err, _ERRLEN), err)
 
     def close(self) -> None:
         if self._h:
@@ -225,8 +248,51 @@ class Scanner:
 
     def database_from_pack(self, pack: "Pack", first: int = 0, count: Optional[int] = None,
                            entries: Optional[Sequence[int]] = None,
-                           ranges: Optional[Sequence[Tuple[int, int]]] = None) -> Database:
-        return Database(self, pack=pack, first=first, count=count, entries=entries, ranges=ranges)
+                           ranges: Optional[Sequence[Tuple[int, int]]] = None, wait: bool = True) -> Database:
+        return Database(self, pack=pack, first=first, count=count, entries=entries, ranges=ranges, wait=wait)
+
+    def set_option(self, name: str, value: int) -> None:
+        """A launch-shape / diagnostic switch between scans (rma_scanner_set_option); the RNAMOTIF_*
+        environment is read once, when the scanner is created."""
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_scanner_set_option(self._h, name.encode(), int(value), err, _ERRLEN), err)
+
+    def warmup(self) -> None:
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_scanner_warmup(self._h, err, _ERRLEN), err)
+
+    def attach(self, db: Database) -> None:
+        """Lay db out for this scanner ahead of its first scan of it (rma_db_attach)."""
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_db_attach(self._h, db._h, err, _ERRLEN), err)
+
+    def scan_begin(self, db: Database) -> None:
+        """The search kernel on its way (rma_scan_begin); scan_end() returns the records."""
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_scan_begin(self._h, db._h, err, _ERRLEN), err)
+
+    def scan_end(self, copy: bool = True) -> np.ndarray:
+        L = lib()
+        hits = C.POINTER(C.c_int32)()
+        n = C.c_int64()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_scan_end(self._h, C.byref(hits), C.byref(n), err, _ERRLEN), err)
+        return self._records(hits, n.value, copy)
+
+    def scan_end_on_device(self) -> int:
+        """End the scan in flight leaving the ordered records in HBM (for Comm.gather); their number."""
+        d = C.c_void_p()
+        n = C.c_int64()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_scan_end_on_device(self._h, C.byref(d), C.byref(n), err, _ERRLEN), err)
+        return n.value
+
+    def _records(self, hits, n: int, copy: bool) -> np.ndarray:
+        stride = self.descr.hit_stride
+        if n == 0:
+            return np.zeros((0, stride), dtype=np.int32)
+        a = np.ctypeslib.as_array(hits, shape=(n * stride,)).reshape(n, stride)
+        return a.copy() if copy else a
 
     def scan(self, db: Database, copy: bool = True) -> np.ndarray:
         """All candidates of db in reference order: int32 array [n, hit_stride].  With
@@ -236,12 +302,7 @@ class Scanner:
         n = C.c_int64()
         err = C.create_string_buffer(_ERRLEN)
         _check(L.rma_scan(self._h, db._h, C.byref(hits), C.byref(n), err, _ERRLEN), err)
-        stride = self.descr.hit_stride
-        if n.value == 0:
-            return np.zeros((0, stride), dtype=np.int32)
-        a = np.ctypeslib.as_array(hits, shape=(n.value * stride,))
-        a = a.reshape(n.value, stride)
-        return a.copy() if copy else a
+        return self._records(hits, n.value, copy)
 
     def scan_device(self, db: Database) -> Tuple[int, float, float]:
         """Device part only: (candidates, search kernel ms, efn kernel ms)."""
@@ -302,6 +363,51 @@ class Replay:
             rc = lib().rma_replay_close(self._h, err, _ERRLEN)
             self._h = None
             _check(rc, err)
+
+
+class Comm:
+    """The native gather of a multi-GPU search (rma_comm_*, rma_gather_hits): RCCL behind the C ABI.
+    One per process.  `broadcast(buf: bytearray)` hands rank 0's 128-byte id to every rank -- with
+    torch.distributed: a broadcast of a uint8 tensor (rnamotif_amd/distributed.py does that)."""
+
+    def __init__(self, rank: int, world: int, device: int, broadcast=None):
+        L = lib()
+        ident = C.create_string_buffer(128)
+        err = C.create_string_buffer(_ERRLEN)
+        if world > 1:
+            if rank == 0:
+                _check(L.rma_comm_unique_id(ident, err, _ERRLEN), err)
+            raw = bytearray(ident.raw)
+            broadcast(raw)
+            ident = C.create_string_buffer(bytes(raw), 128)
+        h = C.c_void_p()
+        _check(L.rma_comm_create(ident, rank, world, device, C.byref(h), err, _ERRLEN), err)
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def gather(self, scanner: Scanner, global_index: Sequence[int], root: int = 0):
+        """The records of every rank's last scan (left in HBM) to `root`: (records [n, stride] on root --
+        rank by rank, each part in order -- else empty, counts per rank)."""
+        L = lib()
+        idx = np.ascontiguousarray(np.asarray(global_index, dtype=np.int32))
+        hits = C.POINTER(C.c_int32)()
+        n = C.c_int64()
+        counts = (C.c_int64 * self.world)()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(L.rma_gather_hits(self._h, scanner._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx), root,
+                                 C.byref(hits), C.byref(n), counts, err, _ERRLEN), err)
+        return scanner._records(hits, n.value, True), [int(c) for c in counts]
+
+    def close(self) -> None:
+        if self._h:
+            lib().rma_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def sort_hits(hits: np.ndarray) -> np.ndarray:
@@ -369,6 +475,11 @@ class Pack:
         arr = _cstr_array([p.encode() for p in paths])
         _check(L.rma_pack_read(arr, len(paths), fmt.encode() if fmt else None, maxslen, threads, C.byref(h), err, _ERRLEN), err)
         return Pack(_handle=h)
+
+    def pin(self) -> None:
+        """Page-lock the packed words: uploads from this pack are DMA, asynchronous (rma_pack_pin)."""
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_pack_pin(self._h, err, _ERRLEN), err)
 
     def lengths(self) -> List[int]:
         L = lib()

@@ -99,6 +99,8 @@ extern "C" int rma_replay_open( rma_descr_t *d, const char *path, rma_replay_t *
 		return 0;
 	}catch( rma::Error &e ){
 		return set_err( err, errlen, e.what() );
+	}catch( std::exception &e ){
+		return set_err( err, errlen, e.what() );
 	}
 }
 
@@ -201,9 +203,14 @@ extern "C" int rma_pack_open( const char *path, rma_pack_t **out, char *err, siz
 	*out = nullptr;
 	rma_pack	*pk = new rma_pack;
 	std::string	e;
-	if( !pk->pf.load( path, e ) ){
+	try{
+		if( !pk->pf.load( path, e ) ){
+			delete pk;
+			return set_err( err, errlen, e.c_str() );
+		}
+	}catch( std::exception &x ){
 		delete pk;
-		return set_err( err, errlen, e.c_str() );
+		return set_err( err, errlen, x.what() );
 	}
 	*out = pk;
 	return 0;
@@ -214,6 +221,7 @@ extern "C" int rma_pack_read( const char *const *paths, int32_t n_paths, const c
 {
 	*out = nullptr;
 	rma_pack	*pk = new rma_pack;
+	try{
 	const int	lim = maxslen > 0 ? maxslen + 1 : 30000000 + 1;		// getargs.c: -N n reads n letters
 	const rma::SeqFormat	sf = rma::seq_format_of( fmt ? fmt : "" );
 	for( int f = 0; f < n_paths; f++ ){
@@ -269,6 +277,10 @@ extern "C" int rma_pack_read( const char *const *paths, int32_t n_paths, const c
 		while( rd.next( rec ) )
 			pk->pf.add( rec );
 		fclose( fp );
+	}
+	}catch( std::exception &x ){
+		delete pk;
+		return set_err( err, errlen, x.what() );
 	}
 	*out = pk;
 	return 0;

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 
 namespace rma {
 
@@ -98,6 +99,9 @@ int cli_main( int argc, char **argv, BackendFactory make_backend )
 		size_t	n = strlen( m );
 		if( n == 0 || m[ n - 1 ] != '\n' )
 			fputc( '\n', stderr );
+		return 1;
+	}catch( std::exception &e ){		// (out of memory and the like: reported, not std::terminate)
+		fprintf( stderr, "%s: %s\n", argc > 0 ? argv[ 0 ] : "rnamotif", e.what() );
 		return 1;
 	}
 }

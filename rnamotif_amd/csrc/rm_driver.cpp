@@ -155,15 +155,21 @@ struct Batch {
 	std::unique_ptr<PackFile>	own;	// (a slice of a packed database on disk has no copy of its own)
 	const PackFile	*pk = nullptr;
 	int	first = 0, count = 0;
+	void	*db = nullptr;			// the batch in HBM (ScanBackend::upload_packed)
 	std::vector<int32_t>	hits;
 	int64_t	n_hits = 0;
 };
 
+// Three stages behind the reader, a thread each, batches handed on in order: upload (the packed words
+// into HBM, on the device's upload stream), scan (kernels, ordering, copy back of the candidates),
+// replay (score program and printer).  A failure anywhere sets aborting_: queued batches and the
+// ones in hand are dropped, not scanned or printed -- the reference leaves at the failing candidate.
 class Pipeline {
 public:
 	Pipeline( ScanBackend &be, Replayer &rp, const rma_program_t &prog, SearchStats &st )
 		: be_( be ), rp_( rp ), prog_( prog ), st_( st )
 	{
+		up_ = std::thread( [ this ](){ up_loop(); } );
 		gpu_ = std::thread( [ this ](){ gpu_loop(); } );
 		out_ = std::thread( [ this ](){ out_loop(); } );
 	}
@@ -172,24 +178,30 @@ public:
 		{
 			std::lock_guard<std::mutex>	lk( mu_ );
 			closing_ = true;
+			if( in_flight_ > 0 )
+				aborting_ = true;	// (unwinding with batches in flight: nobody will read their output)
 		}
 		cv_.notify_all();
+		up_.join();
 		gpu_.join();
 		out_.join();
+		for( std::deque<Batch> *q : { &to_up_, &to_gpu_, &to_out_ } )
+			for( Batch &b : *q )
+				drop( b );
 	}
 	void	submit( Batch &&b )
 	{
 		std::unique_lock<std::mutex>	lk( mu_ );
-		cv_.wait( lk, [ & ]{ return to_gpu_.size() < 2 || failed_; } );
+		cv_.wait( lk, [ & ]{ return to_up_.size() < 2 || aborting_; } );
 		rethrow( lk );
-		to_gpu_.push_back( std::move( b ) );
+		to_up_.push_back( std::move( b ) );
 		in_flight_++;
 		cv_.notify_all();
 	}
 	void	drain()			// every batch submitted so far is printed
 	{
 		std::unique_lock<std::mutex>	lk( mu_ );
-		cv_.wait( lk, [ & ]{ return in_flight_ == 0 || failed_; } );
+		cv_.wait( lk, [ & ]{ return in_flight_ == 0 || aborting_; } );
 		rethrow( lk );
 	}
 private:
@@ -200,71 +212,98 @@ private:
 			throw Error( what_ );
 		}
 	}
+	void	drop( Batch &b )
+	{
+		if( b.db != nullptr && be_.drop_uploaded != nullptr )
+			be_.drop_uploaded( be_.self, b.db );
+		b.db = nullptr;
+	}
 	void	fail_with( const std::string &m )
 	{
 		std::lock_guard<std::mutex>	lk( mu_ );
-		if( !failed_ ){
+		if( !aborting_ ){
 			failed_ = true;
 			what_ = m;
 		}
-		in_flight_ = 0;
-		to_gpu_.clear();
-		to_out_.clear();
+		aborting_ = true;
 		cv_.notify_all();
+	}
+	// take the next batch of `from` (false: the pipeline is closing or aborting)
+	bool	take( std::deque<Batch> &from, Batch &b )
+	{
+		std::unique_lock<std::mutex>	lk( mu_ );
+		cv_.wait( lk, [ & ]{ return !from.empty() || closing_ || aborting_; } );
+		if( aborting_ || from.empty() )
+			return false;
+		b = std::move( from.front() );
+		from.pop_front();
+		cv_.notify_all();
+		return true;
+	}
+	// hand b on to `to` (false: aborting, b is dropped)
+	bool	pass( std::deque<Batch> &to, Batch &b )
+	{
+		std::unique_lock<std::mutex>	lk( mu_ );
+		cv_.wait( lk, [ & ]{ return to.size() < 2 || aborting_; } );
+		if( aborting_ ){
+			lk.unlock();
+			drop( b );
+			return false;
+		}
+		to.push_back( std::move( b ) );
+		cv_.notify_all();
+		return true;
+	}
+	void	up_loop()
+	{
+		for( Batch b; take( to_up_, b ); ){
+			char	err[ 1024 ] = "";
+			const auto	t0 = std::chrono::steady_clock::now();
+			if( be_.upload_packed( be_.self, b.pk, b.first, b.count, &b.db, err, sizeof( err ) ) ){
+				fail_with( std::string( "scan failed: " ) + err );
+				return;
+			}
+			if( timing_ )
+				fprintf( stderr, "[timing] upload of %d entries: %.1f ms (done at +%.1f)\n", b.count,
+					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), lap_clock() );
+			if( !pass( to_gpu_, b ) )
+				return;
+		}
 	}
 	void	gpu_loop()
 	{
-		for( ; ; ){
-			Batch	b;
-			{
-				std::unique_lock<std::mutex>	lk( mu_ );
-				cv_.wait( lk, [ & ]{ return !to_gpu_.empty() || closing_; } );
-				if( to_gpu_.empty() )
-					return;
-				b = std::move( to_gpu_.front() );
-				to_gpu_.pop_front();
-				cv_.notify_all();
-			}
+		for( Batch b; take( to_gpu_, b ); ){
 			char	err[ 1024 ] = "";
 			const int32_t	*hits = nullptr;
 			const auto	t0 = std::chrono::steady_clock::now();
-			if( be_.scan_packed( be_.self, b.pk, b.first, b.count, &hits, &b.n_hits, err, sizeof( err ) ) ){
+			void	*db = b.db;
+			b.db = nullptr;		// (scan_uploaded takes it, whatever it returns)
+			if( be_.scan_uploaded( be_.self, db, &hits, &b.n_hits, err, sizeof( err ) ) ){
 				fail_with( std::string( "scan failed: " ) + err );
-				continue;
+				return;
 			}
 			b.hits.assign( hits, hits + b.n_hits * rma_hit_stride( &prog_ ) );	// (the scanner's buffer is its next scan's)
 			if( timing_ )
 				fprintf( stderr, "[timing] scan of %d entries: %.1f ms, %lld candidates (done at +%.1f)\n", b.count,
 					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), ( long long )b.n_hits, lap_clock() );
-			std::unique_lock<std::mutex>	lk( mu_ );
-			cv_.wait( lk, [ & ]{ return to_out_.size() < 2 || closing_; } );
-			to_out_.push_back( std::move( b ) );
-			cv_.notify_all();
+			if( !pass( to_out_, b ) )
+				return;
 		}
 	}
 	void	out_loop()
 	{
-		for( ; ; ){
-			Batch	b;
-			{
-				std::unique_lock<std::mutex>	lk( mu_ );
-				cv_.wait( lk, [ & ]{ return !to_out_.empty() || ( closing_ && to_gpu_.empty() && in_flight_ == 0 ); } );
-				if( to_out_.empty() )
-					return;
-				b = std::move( to_out_.front() );
-				to_out_.pop_front();
-				cv_.notify_all();
-			}
+		for( Batch b; take( to_out_, b ); ){
 			const auto	t0 = std::chrono::steady_clock::now();
 			try{
 				rp_.replay_packed( *b.pk, b.first, b.hits.data(), b.n_hits, st_ );
 			}catch( Error &e ){
 				fail_with( e.what() );
-				continue;
+				return;
 			}
 			if( timing_ )
 				fprintf( stderr, "[timing] replay of %lld candidates: %.1f ms (done at +%.1f)\n", ( long long )b.n_hits,
 					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), lap_clock() );
+			b = Batch();		// (the batch's own pack goes before the count says it is done)
 			std::lock_guard<std::mutex>	lk( mu_ );
 			if( in_flight_ > 0 )
 				in_flight_--;
@@ -277,12 +316,12 @@ private:
 	SearchStats	&st_;
 	std::mutex	mu_;
 	std::condition_variable	cv_;
-	std::deque<Batch>	to_gpu_, to_out_;
+	std::deque<Batch>	to_up_, to_gpu_, to_out_;
 	int	in_flight_ = 0;
-	bool	closing_ = false, failed_ = false;
+	bool	closing_ = false, failed_ = false, aborting_ = false;
 	const bool	timing_ = getenv( "RNAMOTIF_TIMING" ) != nullptr;
 	std::string	what_;
-	std::thread	gpu_, out_;
+	std::thread	up_, gpu_, out_;
 };
 
 int parser_threads()
@@ -310,7 +349,10 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 	int	ecnt = 0;
 	const int	show_progress = d.int_global( "show_progress", 0 );
 	// (RNAMOTIF_SERIAL: the one-thread loop over text, as the reference has it)
-	const bool	piped = be.scan_packed != nullptr && getenv( "RNAMOTIF_SERIAL" ) == nullptr;
+	const bool	piped = be.upload_packed != nullptr && be.scan_uploaded != nullptr && getenv( "RNAMOTIF_SERIAL" ) == nullptr;
+	// (declared before the pipeline: its threads upload from and print from these packs until they are
+	// joined, so the packs must be the last to go when an error unwinds this function)
+	std::vector<std::unique_ptr<PackFile>>	packs;		// (alive until the last batch is printed)
 	std::unique_ptr<Pipeline>	pl;
 	if( piped )
 		pl.reset( new Pipeline( be, rp, prog, st ) );
@@ -371,7 +413,6 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		pl->submit( std::move( b ) );
 	};
 	// A packed database (rm_pack.h) takes the place of a text file: same entries, same order.
-	std::vector<std::unique_ptr<PackFile>>	packs;		// (alive until the last batch is printed)
 	auto scan_pack = [&]( const std::string &path ){
 		packs.emplace_back( new PackFile );
 		PackFile	&pk = *packs.back();

@@ -18,10 +18,17 @@ struct ScanBackend {
 	void	*self;
 	int	( *scan )( void *self, const char *const *seqs, const int32_t *slens, int n,
 			const int32_t **hits, int64_t *n_hits, char *err, size_t errlen );
-	// optional: scan entries [first, first+count) of a packed database (rm_pack.h) without
-	// going through text; hit records number the entries from 0 = first
-	int	( *scan_packed )( void *self, const PackFile *pk, int first, int count,
-			const int32_t **hits, int64_t *n_hits, char *err, size_t errlen ) = nullptr;
+	// optional: entries [first, first+count) of a packed database (rm_pack.h) without going through
+	// text, in two halves so that a batch is uploaded while the one before is searched:
+	// upload_packed() puts them into HBM and returns a handle; scan_uploaded() searches what the
+	// handle holds -- hit records number the entries from 0 = first -- and releases it, whatever
+	// it returns; drop_uploaded() releases a handle that is not going to be searched.  The pack must
+	// stay as it is until one of the two has been called.
+	int	( *upload_packed )( void *self, const PackFile *pk, int first, int count, void **handle,
+			char *err, size_t errlen ) = nullptr;
+	int	( *scan_uploaded )( void *self, void *handle, const int32_t **hits, int64_t *n_hits,
+			char *err, size_t errlen ) = nullptr;
+	void	( *drop_uploaded )( void *self, void *handle ) = nullptr;
 };
 
 struct SearchStats {

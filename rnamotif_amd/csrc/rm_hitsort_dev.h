@@ -8,7 +8,7 @@
 // 0.3 ms of a 4.4 ms step at 100 Mbase, 1.9 of 38 ms at 1 Gbase).  A record whose header does not
 // fit the key is flagged and the caller falls back to the host sort.
 #pragma once
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
 #include <cstdint>
 
 namespace rma {
@@ -33,5 +33,10 @@ struct DevHitSort {
 	hipError_t	run( const int32_t *d_hits, int64_t n, int w_seq, int w_pos, int w_rank, hipStream_t s );
 	void	release();
 };
+
+// word 0 of every record (the entry's number within one scan's database) becomes index[ word 0 ], the
+// entry's number in the whole database: what a rank of a multi-GPU search does before its records
+// travel (rm_gather.cpp).  Records whose word 0 is outside 0 .. n_index-1 are left as they are.
+hipError_t	relabel_entries( int32_t *d_hits, int64_t n, int stride, const int32_t *d_index, int32_t n_index, hipStream_t s );
 
 }	// namespace rma

@@ -58,7 +58,27 @@ hit_gather_kernel( const int32_t *hits, const unsigned *perm, const unsigned lon
 	}
 }
 
+__global__ void __launch_bounds__( 256 )
+hit_relabel_kernel( int32_t *hits, long long n, int stride, const int32_t *index, int n_index )
+{
+	const long long	i = blockIdx.x * 256ll + threadIdx.x;
+	if( i >= n )
+		return;
+	const int32_t	e = hits[ i * stride ];
+	if( e >= 0 && e < n_index )
+		hits[ i * stride ] = index[ e ];
+}
+
 }	// namespace
+
+hipError_t relabel_entries( int32_t *d_hits, int64_t n, int stride, const int32_t *d_index, int32_t n_index, hipStream_t s )
+{
+	if( n <= 0 )
+		return hipSuccess;
+	hipLaunchKernelGGL( hit_relabel_kernel, dim3( unsigned( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, s,
+		d_hits, ( long long )n, stride, d_index, int( n_index ) );
+	return hipGetLastError();
+}
 
 void DevHitSort::release()
 {

@@ -1,0 +1,108 @@
+// rm_kernels.h -- what the host half of the scanner (rm_scanner.cpp) and the kernel translation
+// units (rm_scan_inst_*.hip, rm_scan_kernel.h) share: the views of a database and of the hit buffer
+// a launch gets, the launch-shape constants, and one launcher per kernel instance.  The kernels
+// are templates (rm_scan_kernel.h); every instance lives in a translation unit of its own so that
+// they compile side by side.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include "rm_dev_program.h"
+
+// ---------------------------------------------------------------- device views
+struct DbView {
+	const uint32_t	*codes, *amask;
+	const int64_t	*base_off;	// [n_seq]   first base of sequence s (multiple of 32)
+	const int32_t	*slen;		// [n_seq]
+	const int64_t	*tile_start;	// [n_seq+1] prefix sum of tiles over sequences
+	const int32_t	*tile_seq;	// [n_tiles] sequence of every tile (saves a search per tile)
+	const int32_t	*pos_lo, *pos_hi;	// [n_seq] or null: only start positions lo <= szero < hi (each strand)
+	int32_t	n_seq, strands, tile_t;
+	int64_t	n_tiles;
+};
+
+struct HitBuf {
+	int32_t	*hits;
+	unsigned long long	*count;		// candidates found (may exceed cap)
+	unsigned long long	*ticket;	// next tile
+	int64_t	cap;
+	unsigned	*spill;			// [gridDim.x][spill_cap] work queue items that did not fit the LDS queue
+	int	spill_cap;
+	unsigned	*pool;			// [gridDim.x][pool_cap][3] pooled instance: items that passed the tile's tests
+	int	pool_cap, pool_min;	// ... searched once pool_min of them have come together
+	int	pool_refill;		// idle lanes of a wave that pop together
+};
+
+// ---------------------------------------------------------------- launch-shape constants
+#ifndef QCAP
+#define QCAP		1024		// work queue entries per workgroup
+#endif
+// Lean path records of one lane in LDS, 6 bytes per level (LdsRecs, rm_scan_kernel.h)
+#define LEAN_REC_BYTES	6
+// General path records of one lane in LDS (rmd_grec_t, 12 bytes per level: LdsGRecs)
+#define GEN_REC_BYTES	12
+// queue of continuations of the general instance (LdsSplit)
+#define DEEP_QUEUE	128
+#ifndef SEARCH_WAVES_PER_SIMD
+#define SEARCH_WAVES_PER_SIMD	4
+#endif
+#ifndef GENERAL_WAVES_PER_SIMD
+#define GENERAL_WAVES_PER_SIMD	4
+#endif
+#ifndef RMD_KIND_PK
+#define RMD_KIND_PK	1	// improper (pseudoknot) helices
+#define RMD_KIND_TQ	2	// parallel helices, triplexes, 4-plexes
+#endif
+// (... three with 168 registers for descriptors with triplexes / 4-plexes: qu+tr 46.4 -> 39.2 ms, where
+// pk1 goes 7.5 -> 8.6 ms)
+#define GENERAL_WAVES( kinds_ )	( ( ( kinds_ ) & RMD_KIND_TQ ) ? 3 : GENERAL_WAVES_PER_SIMD )
+#ifndef SHORT_GROUP
+#define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
+#endif
+#define SHORT_ENTRY_MEAN	4000	// ... which are those whose entries average less than this
+#define SPILL_ITEMS		8192	// queue items per workgroup that may overflow into HBM (32 KB each, 64 MB in all)
+#define SEARCH_BLOCK		256	// lanes of a search workgroup
+#define EFN_BLOCK		256	// lanes of an efn workgroup
+
+// ---------------------------------------------------------------- kernel instances
+// Which instance of rma_search_kernel a launch takes (rma_scan_device picks it from the descriptor
+// and the database's shape).
+enum rmk_instance {
+	RMK_LEAN_POOL = 0,	// lean, pass B over a pool of survivors (the headline instance)
+	RMK_LEAN_GROUP,		// lean, groups of SHORT_GROUP small tiles (databases of short entries)
+	RMK_LEAN_TILE,		// lean, pass B tile by tile
+	RMK_GEN_PLAIN,		// general, no pseudoknot, no triplex / 4-plex
+	RMK_GEN_PK,
+	RMK_GEN_TQ,
+	RMK_GEN_PKTQ,
+	RMK_N_INSTANCES
+};
+
+struct rmk_search_args {
+	const rmd_program_t	*d_prog;
+	int	prog_bytes, qcap;
+	DbView	db;
+	HitBuf	hb;
+	int	tile_bytes, dbg;
+};
+
+// Launch instance `inst` with `grid` workgroups of SEARCH_BLOCK lanes and lds bytes of dynamic LDS on s.
+hipError_t	rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+// the launchers behind it, one translation unit each (rm_scan_inst_*.hip)
+hipError_t	rmk_launch_lean_pool( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_lean_group( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_lean_tile( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_plain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_pk( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_tq( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_pktq( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+
+struct rmk_efn_args {
+	const rmd_program_t	*d_prog;
+	DbView	db;
+	int32_t	*hits;
+	long long	n_hits;
+	const int16_t	*t16;		// efn's tables as int16 (RME_N16 entries, padded to 8), or null
+	const int32_t	*tlkey, *loginc;
+	const rma_efn2data_t	*e2;	// efn2's tables, or null
+};
+hipError_t	rmk_launch_efn( int grid, hipStream_t s, const rmk_efn_args &a );

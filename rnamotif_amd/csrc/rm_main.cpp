@@ -30,18 +30,31 @@ int hip_scan( void *self, const char *const *seqs, const int32_t *slens, int n,
 	return rma_scan( hb->sc, hb->db, hits, n_hits, err, errlen );
 }
 
-int hip_scan_packed( void *self, const rma::PackFile *pk, int first, int count,
-	const int32_t **hits, int64_t *n_hits, char *err, size_t errlen )
+// the driver holds a PackFile; the ABI wants the handle that wraps one
+int hip_upload_packed( void *self, const rma::PackFile *pk, int first, int count, void **handle, char *err, size_t errlen )
 {
 	HipBackend	*hb = ( HipBackend * )self;
-	if( hb->db != nullptr ){
-		rma_db_destroy( hb->db );
-		hb->db = nullptr;
-	}
-	// the driver holds a PackFile; the ABI wants the handle that wraps one
-	if( rma_db_create_packed( hb->sc, rma_pack_wrap( pk ), first, count, &hb->db, err, errlen ) )
+	rma_db_t	*db = nullptr;
+	*handle = nullptr;
+	// (without waiting: the copies run on the upload stream, the scan waits for them on the device)
+	if( rma_db_create_packed_async( hb->sc, rma_pack_wrap( pk ), first, count, &db, err, errlen ) )
 		return 1;
-	return rma_scan( hb->sc, hb->db, hits, n_hits, err, errlen );
+	*handle = db;
+	return 0;
+}
+
+int hip_scan_uploaded( void *self, void *handle, const int32_t **hits, int64_t *n_hits, char *err, size_t errlen )
+{
+	HipBackend	*hb = ( HipBackend * )self;
+	rma_db_t	*db = ( rma_db_t * )handle;
+	const int	rc = rma_scan( hb->sc, db, hits, n_hits, err, errlen );
+	rma_db_destroy( db );		// (its block of HBM waits for the next batch)
+	return rc;
+}
+
+void hip_drop_uploaded( void *, void *handle )
+{
+	rma_db_destroy( ( rma_db_t * )handle );
 }
 
 rma::ScanBackend make_hip( const rma_program_t *prog, const rma_efndata_t *efn, const rma_efn2data_t *efn2 )
@@ -53,7 +66,10 @@ rma::ScanBackend make_hip( const rma_program_t *prog, const rma_efndata_t *efn, 
 		rma::fail( "%s", err );
 	if( efn2 != nullptr && rma_scanner_set_efn2data( hb->sc, efn2, err, sizeof( err ) ) )
 		rma::fail( "%s", err );
-	return rma::ScanBackend{ hb, hip_scan, hip_scan_packed };
+	// first-use set-up of the runtime now, not in the first batch (a failure here would show there too)
+	if( !getenv( "RNAMOTIF_NO_WARMUP" ) )
+		( void )rma_scanner_warmup( hb->sc, err, sizeof( err ) );
+	return rma::ScanBackend{ hb, hip_scan, hip_upload_packed, hip_scan_uploaded, hip_drop_uploaded };
 }
 
 }	// namespace

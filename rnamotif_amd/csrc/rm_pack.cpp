@@ -6,6 +6,7 @@
 #include <thread>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/stat.h>
 
 namespace rma {
 
@@ -212,6 +213,16 @@ bool PackFile::open( const std::string &path, std::string &err )
 			err = bad;
 			return false;
 		}
+	{
+		// the arrays the header announces must be in the file: a truncated or corrupt pack is refused
+		// before anything of the announced sizes is allocated
+		struct stat	sb;
+		const int64_t	need = 8 + int64_t( sizeof( hdr ) ) + 20 * hdr[ 0 ] + 4 * ( hdr[ 1 ] + hdr[ 2 ] ) + hdr[ 3 ] + hdr[ 4 ];
+		if( fstat( src->fd, &sb ) != 0 || int64_t( sb.st_size ) < need ){
+			err = bad;
+			return false;
+		}
+	}
 	const int64_t	n = hdr[ 0 ];
 	int64_t	at = 8 + int64_t( sizeof( hdr ) );
 	slen.resize( size_t( n ) );

@@ -40,6 +40,19 @@ struct PackFile {
 	std::vector<int32_t>	slen;
 	std::vector<int64_t>	base_off, exc_off;
 	PackWords	codes, amask;
+	// codes / amask page-locked for DMA (rma_pack_pin, rm_scanner.cpp): released before the vectors
+	// above go away (members are destroyed in reverse order), handed on when the pack is moved
+	struct Pin {
+		void	*c = nullptr, *m = nullptr;
+		void	( *unreg )( void * ) = nullptr;
+		Pin() = default;
+		Pin( Pin &&o ) noexcept : c( o.c ), m( o.m ), unreg( o.unreg ) { o.unreg = nullptr; }
+		Pin &operator=( Pin &&o ) noexcept { release(); c = o.c; m = o.m; unreg = o.unreg; o.unreg = nullptr; return *this; }
+		Pin( const Pin & ) = delete;
+		Pin &operator=( const Pin & ) = delete;
+		void	release() { if( unreg ){ if( c ) unreg( c ); if( m ) unreg( m ); unreg = nullptr; } }
+		~Pin() { release(); }
+	}	pin;
 	std::vector<char>	exc, text;
 	std::vector<int64_t>	sid_off, sdef_off;	// into text (built on load)
 	int64_t	total_bases = 0;

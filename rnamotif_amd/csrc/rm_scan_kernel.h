@@ -1,5 +1,7 @@
-// rm_scan_hip.hip -- the scan path on MI355X (gfx950): search kernel, efn
-// kernel, and the scanner / database halves of the C ABI (include/rnamotif_amd.h).
+// rm_scan_kernel.h -- device code of the scan path on MI355X (gfx950): the search kernel and
+// the efn kernel as templates.  Included by the rm_scan_inst_*.hip translation units only, each
+// of which instantiates some of the kernel's instances behind the launchers rm_kernels.h declares
+// (one file per class of descriptor, so that the instances compile side by side).
 //
 // What runs here is the reference's RM_find_motif() for every start position of
 // every sequence and strand (/root/reference/src/find_motif.c:164-207), one
@@ -15,15 +17,9 @@
 // as one byte per base (codes 0..4, reverse strand complemented on the fly) and
 // keeps the motif program in LDS as well.  Tiles are handed out through an
 // atomic ticket so that long searches do not stall a fixed schedule.
+#pragma once
 #include <hip/hip_runtime.h>
-#include <algorithm>
-#include <cstdio>
-#include <cstring>
-#include <numeric>
-#include <chrono>
-#include <cmath>
-#include <string>
-#include <vector>
+#include <cstdint>
 
 #define RMD_HD		__host__ __device__ inline
 #define RMD_FN		static __device__ inline
@@ -32,35 +28,7 @@
 #include "rm_scan_core.h"
 #include "rm_efn_core.h"
 #include "rm_efn2_core.h"
-#include "rm_fasta.h"
-#include "rm_pack.h"
-#include "rm_hitsort.h"
-#include "rm_hitsort_dev.h"
-#include "rnamotif_amd.h"
-
-// ---------------------------------------------------------------- device views
-struct DbView {
-	const uint32_t	*codes, *amask;
-	const int64_t	*base_off;	// [n_seq]   first base of sequence s (multiple of 32)
-	const int32_t	*slen;		// [n_seq]
-	const int64_t	*tile_start;	// [n_seq+1] prefix sum of tiles over sequences
-	const int32_t	*tile_seq;	// [n_tiles] sequence of every tile (saves a search per tile)
-	const int32_t	*pos_lo, *pos_hi;	// [n_seq] or null: only start positions lo <= szero < hi (each strand)
-	int32_t	n_seq, strands, tile_t;
-	int64_t	n_tiles;
-};
-
-struct HitBuf {
-	int32_t	*hits;
-	unsigned long long	*count;		// candidates found (may exceed cap)
-	unsigned long long	*ticket;	// next tile
-	int64_t	cap;
-	unsigned	*spill;			// [gridDim.x][spill_cap] work queue items that did not fit the LDS queue
-	int	spill_cap;
-	unsigned	*pool;			// [gridDim.x][pool_cap][3] pooled instance: items that passed the tile's tests
-	int	pool_cap, pool_min;	// ... searched once pool_min of them have come together
-	int	pool_refill;		// idle lanes of a wave that pop together
-};
+#include "rm_kernels.h"
 
 __device__ inline int db_code( const DbView &db, int64_t base )	// forward strand code of absolute base
 {
@@ -88,15 +56,11 @@ struct DevSink {
 	}
 };
 
-#ifndef QCAP
-#define QCAP		1024		// work queue entries per workgroup
-#endif
 
 // Lean path records of one lane in LDS, 6 bytes per level: windows of lean descriptors are
 // shorter than 4096 (rmd_build), so window start and saved end take 12 bits each, the next
 // end position (down to -2) 13, the helix length 6, the phase 1.
 // Level k: a dword at lo[ k * BLOCK ] and a half word at hi[ k * BLOCK ], lane-contiguous.
-#define LEAN_REC_BYTES	6
 template< int BLOCK >
 struct LdsRecs {
 	uint32_t	*lo;
@@ -127,7 +91,6 @@ struct LdsRecs {
 // w[ ( 3 * k + j ) * BLOCK ], lane-contiguous, so a wave's access is conflict free whatever
 // levels its lanes are on.  Dword 0: window start | saved window end; dword 1: next end position |
 // first loop variable; dword 2: second loop variable | helix length | phase.
-#define GEN_REC_BYTES	12
 template< int BLOCK >
 struct LdsGRecs {
 	uint32_t	*w;
@@ -193,7 +156,6 @@ struct LdsGRecs {
 // rmd_gen_step()'s hand-over of the alternatives of the split level: a queue of continuations in
 // LDS, walked in the tile's second round.  Entry: the work item, the alternative's number, and
 // two words per level 0..S (LdsGRecs::set_before).  A full queue refuses: the lane walks on itself.
-#define DEEP_QUEUE	128
 struct LdsSplit {
 	int	S;
 	uint32_t	*dq;
@@ -451,26 +413,14 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 		}
 
 // ---------------------------------------------------------------- search kernel
-#ifndef SEARCH_WAVES_PER_SIMD
-#define SEARCH_WAVES_PER_SIMD	4
-#endif
 // LEAN: the descriptor has only ss and proper helices (rmd_program_t::lean_ok) -- pass B keeps
 // 8 bytes of state per level in LDS; the general state machine is not compiled into that
 // instance at all (no scratch frames, fewer registers).
 // (the general instance is bound by the latency of its dependent LDS accesses: four workgroups per
 // CU where its records, 12 bytes per level and lane, leave room for them -- measured against three
 // at 168 registers and against out-of-line level generators, profiles/matrix_r2.sh)
-#ifndef GENERAL_WAVES_PER_SIMD
-#define GENERAL_WAVES_PER_SIMD	4
-#endif
 // (... three with 168 registers for descriptors with triplexes / 4-plexes: qu+tr 46.4 -> 39.2 ms, where
 // pk1 goes 7.5 -> 8.6 ms)
-#define GENERAL_WAVES( kinds_ )	( ( ( kinds_ ) & RMD_KIND_TQ ) ? 3 : GENERAL_WAVES_PER_SIMD )
-#ifndef SHORT_GROUP
-#define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
-#endif
-#define SHORT_ENTRY_MEAN	4000
-#define SPILL_ITEMS		8192	// queue items per workgroup that may overflow into HBM (32 KB each, 64 MB in all)	// ... which are those whose entries average less than this
 // G: tiles per workgroup pass.  G == 1: one tile, all lanes on it.  G > 1 (databases of short
 // entries, lean descriptors only): a group of G small tiles, each in its own LDS slot and
 // pre-filtered by one wave, feeding ONE work queue -- a tile of a 500 base entry yields a few
@@ -1268,7 +1218,6 @@ struct DevSeq {
 // workgroup, every lane keeps the base codes and partners of its call in LDS while it is no
 // longer than EFN_CACHE bases (a cloverleaf is under 96) -- 136 KB in all -- and the candidates
 // are taken in a grid-stride loop, so the staging is paid once per CU and four waves share it.
-#define EFN_BLOCK	256
 #define EFN_CACHE	96
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK )
@@ -1300,777 +1249,16 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 	}
 }
 
-// ---------------------------------------------------------------- host side
-#define HIPCHK( call )	do{ hipError_t e_ = ( call ); if( e_ != hipSuccess ){ \
-		snprintf( err, errlen, "%s: %s", #call, hipGetErrorString( e_ ) ); return 1; } }while( 0 )
-
-struct rma_scanner {
-	rma_program_t	prog;
-	rmd_program_t	dprog;
-	int	device = 0;
-	hipStream_t	stream = nullptr;
-	hipEvent_t	ev[ 4 ] = { nullptr, nullptr, nullptr, nullptr };
-	rma_efn2data_t	*d_efn2 = nullptr;	// efn2() tables, global memory
-	bool	need_efn2 = false;
-	rmd_program_t	*d_prog = nullptr;	// compact image, prog_bytes long
-	int	prog_bytes = 0;
-	int	qcap = QCAP;		// work queue entries per workgroup
-	int16_t	*d_t16 = nullptr;
-	int32_t	*d_tlkey = nullptr, *d_loginc = nullptr;
-	bool	have_efn = false;
-	int32_t	*d_hits = nullptr;
-	int64_t	hit_cap = 0;
-	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
-	unsigned	*d_spill = nullptr;		// [grid_blocks][spill_cap] queue overflow of every workgroup
-	int	spill_cap = 0;
-	unsigned	*d_pool = nullptr;		// [grid_blocks][pool_cap][3] pooled instance: items waiting for pass B
-	int	pool_cap = 0, pool_min = 1024;
-	int32_t	*h_raw = nullptr;		// pinned
-	size_t	h_raw_cap = 0;
-	std::vector<int32_t>	h_sorted;
-	std::vector<rma::HitKey>	keys, keys_tmp;
-	rma::DevHitSort	dsort;		// ordering on the device (rm_hitsort_dev.h)
-	unsigned long long	*h_ctr = nullptr;	// pinned: the counters a launch leaves
-	int	tile_t = 2048;
-	int	grid_blocks = 0;
-};
-
-struct rma_db {
-	rma_scanner	*sc;
-	int	device = 0;		// (kept here: a database may outlive its scanner)
-	uint32_t	*d_codes = nullptr, *d_amask = nullptr;
-	int64_t	*d_base_off = nullptr, *d_tile_start = nullptr;
-	int32_t	*d_tile_seq = nullptr;
-	int	tile_t = 0, qcap = 0, group = 1;	// launch shape of this database (see db_upload)
-	int32_t	*d_slen = nullptr, *d_pos_lo = nullptr, *d_pos_hi = nullptr;
-	int32_t	n_seq = 0, max_slen = 0;
-	int64_t	n_tiles = 0, total_bases = 0;
-	int	strands = 2;
-};
-
-extern "C" void rma_db_destroy( rma_db_t *db );
-extern "C" void rma_scanner_destroy( rma_scanner_t *sc );
-
-static void build_tables16( const rma_efndata_t *ed, std::vector<int16_t> &t16, std::vector<int32_t> &tlkey )
-{
-	t16.assign( ( RME_N16 + 7 ) / 8 * 8, 0 );	// padded for 16-byte staging loads
-	tlkey.assign( 100, -1 );
-	auto put = [&]( int off, const int32_t *src, int n ){
-		for( int i = 0; i < n; i++ ){
-			int	v = src[ i ];
-			t16[ off + i ] = int16_t( v > 32767 ? 32767 : v < -32768 ? -32768 : v );
-		}
-	};
-	put( RME_INTER, ed->inter, 31 );
-	put( RME_BULGE, ed->bulge, 31 );
-	put( RME_HAIRPIN, ed->hairpin, 31 );
-	put( RME_DANGLE, &ed->dangle[ 0 ][ 0 ][ 0 ][ 0 ], 250 );
-	put( RME_POPPEN, ed->poppen, 5 );
-	put( RME_EPARAM, ed->eparam, 16 );
-	int32_t	misc[ 9 ] = { ed->maxpen, ed->auend, ed->gubonus, ed->cslope, ed->cint, ed->c3, ed->gail,
-		ed->ntriloops, ed->ntloops };
-	put( RME_MISC, misc, 9 );
-	for( int k = 0; k < 50; k++ ){
-		// a key that does not fit 15 bits can never equal a computed key's low part
-		// by accident: store -1 (no computed key is negative)
-		int	key = k < ed->ntriloops ? ed->triloops[ k ][ 0 ] : -1;
-		t16[ RME_TRIKEY + k ] = int16_t( key >= 0 && key <= 32767 ? key : -1 );
-		t16[ RME_TRIVAL + k ] = int16_t( k < ed->ntriloops ? ed->triloops[ k ][ 1 ] : 0 );
-	}
-	for( int k = 0; k < 100; k++ ){
-		tlkey[ k ] = k < ed->ntloops ? ed->tloops[ k ][ 0 ] : -1;
-		t16[ RME_TLVAL + k ] = int16_t( k < ed->ntloops ? ed->tloops[ k ][ 1 ] : 0 );
-	}
-	put( RME_STACK, &ed->stack[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
-	put( RME_TSTKH, &ed->tstkh[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
-	put( RME_TSTKI, &ed->tstki[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
-	put( RME_SINT2, &ed->sint2[ 0 ][ 0 ][ 0 ][ 0 ], 900 );
-	put( RME_ASINT, &ed->asint1x2[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 4500 );
-	put( RME_SINT4, &ed->sint4[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 22500 );
-}
-
-extern "C" int rma_device_count( void )
-{
-	int	n = 0;
-	if( hipGetDeviceCount( &n ) != hipSuccess )
-		return 0;
-	return n;
-}
-
-// LDS of one search workgroup: program image | queue | tile | 6 bit vectors | lean records
-static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1 )
-{
-	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
-	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
-		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
-	lds += lean ? size_t( dp.n_searches ) * 256 * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * 256 * 4;
-	if( !lean && dp.split_s >= 0 )		// resume states of the levels up to the split level, queue of continuations
-		lds += size_t( dp.split_s + 1 ) * 256 * 8 + size_t( DEEP_QUEUE ) * ( 2 + 2 * ( dp.split_s + 1 ) ) * 4;
-	return lds;
-}
-
-extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_t *efn, int device,
-	rma_scanner_t **out, char *err, size_t errlen )
-{
-	*out = nullptr;
-	rma_scanner	*sc = new rma_scanner;
-	// every early return below releases the scanner and what it holds by then
-	struct ScGuard { rma_scanner *p; ~ScGuard(){ if( p ) rma_scanner_destroy( p ); } }	guard{ sc };
-	sc->prog = *prog;
-	// (host work first: a descriptor outside the device limits is refused with its reason whether
-	// or not a device is there to refuse it for)
-	if( rmd_build( prog, &sc->dprog, err, errlen ) )
-		return 1;
-	int	ndev = 0;
-	if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 ){
-		snprintf( err, errlen, "no HIP device available: the rnamotif scan path runs on the GPU only" );
-		return 1;
-	}
-	if( device < 0 || device >= ndev ){
-		snprintf( err, errlen, "device %d out of range (0..%d)", device, ndev - 1 );
-		return 1;
-	}
-	if( const char *sb = getenv( "RNAMOTIF_BUDGET" ) )		// launch-shape switch: iterations per step
-		sc->dprog.step_budget = std::max( 4, atoi( sb ) );
-	for( int k = 0; k < prog->n_efn_sites; k++ ){
-		if( prog->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
-			sc->need_efn2 = true;	// tables come with rma_scanner_set_efn2data(), checked at the first scan
-		else if( efn == nullptr ){
-			snprintf( err, errlen, "the program has efn() call sites but no energy tables were given" );
-			return 1;
-		}
-	}
-	sc->device = device;
-	HIPCHK( hipSetDevice( device ) );
-	HIPCHK( hipStreamCreate( &sc->stream ) );
-	for( int i = 0; i < 4; i++ )
-		HIPCHK( hipEventCreate( &sc->ev[ i ] ) );
-	{
-		// the device gets the compact image; sc->dprog stays the full struct for the host
-		std::vector<char>	img( sizeof( rmd_program_t ) );
-		sc->prog_bytes = int( rmd_make_image( &sc->dprog, img.data() ) );
-		HIPCHK( hipMalloc( &sc->d_prog, size_t( sc->prog_bytes ) ) );
-		HIPCHK( hipMemcpy( sc->d_prog, img.data(), size_t( sc->prog_bytes ), hipMemcpyHostToDevice ) );
-	}
-	HIPCHK( hipMalloc( &sc->d_counters, 96 * sizeof( unsigned long long ) ) );
-	if( efn != nullptr ){
-		std::vector<int16_t>	t16;
-		std::vector<int32_t>	tlkey;
-		build_tables16( efn, t16, tlkey );
-		HIPCHK( hipMalloc( &sc->d_t16, t16.size() * sizeof( int16_t ) ) );
-		HIPCHK( hipMemcpy( sc->d_t16, t16.data(), t16.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
-		HIPCHK( hipMalloc( &sc->d_tlkey, tlkey.size() * sizeof( int32_t ) ) );
-		HIPCHK( hipMemcpy( sc->d_tlkey, tlkey.data(), tlkey.size() * sizeof( int32_t ), hipMemcpyHostToDevice ) );
-		HIPCHK( hipMalloc( &sc->d_loginc, RMA_EFN_LOGINC * sizeof( int32_t ) ) );
-		HIPCHK( hipMemcpy( sc->d_loginc, efn->loginc, RMA_EFN_LOGINC * sizeof( int32_t ), hipMemcpyHostToDevice ) );
-		sc->have_efn = true;
-	}
-	hipDeviceProp_t	prop;
-	HIPCHK( hipGetDeviceProperties( &prop, device ) );
-	sc->grid_blocks = prop.multiProcessorCount * 8;
-	sc->spill_cap = SPILL_ITEMS;
-	if( const char *sp = getenv( "RNAMOTIF_SPILL" ) )	// tests: 0 = overflow searched in place
-		sc->spill_cap = std::max( 0, atoi( sp ) );
-	HIPCHK( hipMalloc( &sc->d_spill, std::max<size_t>( size_t( sc->grid_blocks ) * sc->spill_cap, 1 ) * sizeof( unsigned ) ) );
-	if( sc->dprog.lean_ok ){
-		// The search of a tile ends with a few long-running items on a few lanes, so fewer,
-		// larger tiles are better as long as four workgroups still share a CU's 160 KB of LDS
-		// (trna.descr, ms per 100 Mbase: T = 2048 6.97, 4096 5.87, 6144 5.40 with 8-byte records;
-		// 6656 4.38, 9984 3.99 with 6-byte records; one step further only three fit: 5.0) and the
-		// work queue still holds what the pre-filter lets through: on random sequence a start
-		// position yields n_rank * P( first minlen pairs hold, at most lim mispairs ) items.
-		const rmd_program_t	&dp = sc->dprog;
-		const rmd_elem_t	&e0 = dp.elems[ dp.searches[ 0 ] ];
-		double	density = 1.0;
-		if( e0.type == RMA_T_H5 && e0.pairset >= 0 && e0.minlen >= 1 ){
-			const uint32_t	m2 = rmd_pairsets( &dp )[ e0.pairset ].mat2;
-			int	np = 0;
-			for( int a = 0; a < 4; a++ )
-				for( int b = 0; b < 4; b++ )
-					np += ( m2 >> ( a * 5 + b ) ) & 1;
-			const double	pp = np / 16.0;
-			const int	lim = ( e0.ends & RMA_5PAIRED ) ? e0.mplim : std::max( e0.mplim, 1 );
-			double	p = 0, comb = 1;
-			for( int m = 0; m <= lim && m <= e0.minlen; m++ ){
-				p += comb * std::pow( pp, e0.minlen - m ) * std::pow( 1 - pp, m );
-				comb = comb * ( e0.minlen - m ) / ( m + 1 );
-			}
-			const int	w = dp.w_winsize;
-			const int	n_rank = ( e0.maxglen != RMA_UNBOUNDED && e0.maxglen < w ? e0.maxglen : w ) - e0.minglen + 1;
-			density = std::min( 1.0, p ) * std::max( 1, n_rank );
-		}
-		if( dp.lit_re >= 0 ){
-			// ... and only where the best literal occurs at an allowed offset
-			const rmd_regex_t	&lre = rmd_regexes( &dp )[ dp.lit_re ];
-			double	pl = 1.0;
-			for( int j = 0; j < lre.n_states; j++ ){
-				int	n = 0;
-				for( int c = 0; c < 4; c++ )
-					n += int( ( lre.accept[ c ] >> j ) & 1 );
-				pl *= n / 4.0;
-			}
-			density *= std::min( 1.0, pl * ( dp.lit_hi - dp.lit_lo + 1 ) );
-		}
-		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64;	// (static __shared__: 32 bytes)
-		// What the LDS queue cannot hold spills to HBM at 4 bytes per item, so LDS goes to the tile
-		// first and the queue gets what is left, up to the expected number of items (trna.descr:
-		// queue 1024 / T 9984 3.99 ms, 512 / 11008 3.94, 256 / 11520 3.91 -- the last spills a
-		// third of its items for that 1 %: the queue starts at 512).  A tile should still not
-		// produce more than half the spill area on average.
-		const int	q_min = 512;
-		sc->tile_t = 2048;
-		for( int t = 16384; t >= 2048; t -= 256 )
-			if( search_lds_bytes( sc->prog_bytes, dp, t, true, q_min ) <= budget &&
-				density * t * 1.1 <= q_min + std::max( sc->spill_cap, 2 * 512 ) / 2 ){
-				sc->tile_t = t;
-				break;
-			}
-		sc->qcap = q_min;
-		const int	q_want = int( std::min( 8192.0, std::ceil( density * sc->tile_t * 1.2 / 256 ) * 256 ) );
-		while( sc->qcap + 256 <= q_want && search_lds_bytes( sc->prog_bytes, dp, sc->tile_t, true, sc->qcap + 256 ) <= budget )
-			sc->qcap += 256;
-	}
-	if( !sc->dprog.lean_ok ){
-		// general instance: its records take 12 bytes per level and lane of LDS next to the tile;
-		// as many workgroups per CU as still leave a tile of a few thousand positions (what the
-		// queue cannot hold spills to HBM)
-		sc->qcap = 512;
-		sc->tile_t = 1024;
-		bool	found = false;
-		int	kinds = 0;
-		for( int k = 0; k < sc->dprog.n_searches; k++ ){
-			const int	t = sc->dprog.elems[ sc->dprog.searches[ k ] ].type;
-			if( t == RMA_T_P5 || t == RMA_T_T1 || t == RMA_T_Q1 )
-				kinds |= RMD_KIND_TQ;
-		}
-		for( int wg = GENERAL_WAVES( kinds ); wg >= 1 && !found; wg-- ){
-			const size_t	budget = ( 160 * 1024 ) / wg - 2560;	// (static __shared__ -- 1 KB of it the pre-filter's wave buffers -- and allocation granules)
-			for( int t = 8192; t >= ( wg > 1 ? 3072 : 1024 ); t -= 256 )
-				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, false, sc->qcap ) <= budget ){
-					sc->tile_t = t;
-					found = true;
-					break;
-				}
-		}
-	}
-	if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )
-		if( atoi( qq ) >= 64 && atoi( qq ) <= 16384 )
-			sc->qcap = ( atoi( qq ) + 3 ) & ~3;	// (what follows the queue in LDS is read 8 bytes at a time)
-	const char	*tt = getenv( "RNAMOTIF_TILE" );
-	if( tt != nullptr && atoi( tt ) > 0 && atoi( tt ) <= 16384 )
-		sc->tile_t = atoi( tt );
-	// room for the candidates of a few hundred Mbase at the densities of the reference's descriptors
-	// (63 per Mbase for trna.descr); a scan that finds more is repeated into a buffer of the right
-	// size (count-then-emit, rma_scan_device)
-	sc->hit_cap = 1 << 17;
-	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
-	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_ctr ), 4 * sizeof( unsigned long long ), hipHostMallocDefault ) );
-	// the ordering's buffers, and one pass over whatever the hit buffer holds so that its kernels are
-	// loaded: 12 ms that would otherwise fall into the first scan
-	if( sc->dsort.reserve( sc->hit_cap, sc->dprog.hit_stride ) == hipSuccess ){
-		( void )sc->dsort.run( sc->d_hits, 4096, 10, 20, 8, sc->stream );
-		( void )hipStreamSynchronize( sc->stream );
-	}
-	( void )hipGetLastError();
-	guard.p = nullptr;
-	*out = sc;
-	// One scan of eight start positions, so that what the runtime sets up on first use (code objects of
-	// the kernel instance this descriptor takes, the first device allocations of a database) belongs to
-	// the creation of the scanner and not to the first batch of a search: 15-50 ms there.  All 'a':
-	// nothing pairs, whatever the descriptor, so no helix is ever walked.
-	if( !getenv( "RNAMOTIF_NO_WARMUP" ) && sc->prog.dminlen <= 2000 ){
-		const std::string	warm( size_t( std::max( sc->prog.dminlen, 1 ) + 7 ), 'a' );
-		const char	*seqs[ 1 ] = { warm.c_str() };
-		const int32_t	lens[ 1 ] = { int32_t( warm.size() ) };
-		rma_db_t	*wdb = nullptr;
-		char	werr[ 256 ];
-		if( rma_db_create( sc, seqs, lens, 1, &wdb, werr, sizeof( werr ) ) == 0 ){
-			const int32_t	*wh = nullptr;
-			int64_t	wn = 0;
-			( void )rma_scan( sc, wdb, &wh, &wn, werr, sizeof( werr ) );	// (efn2 tables not set yet: refused, harmless)
-			rma_db_destroy( wdb );
-		}
-		( void )hipGetLastError();
-	}
-	return 0;
-}
-
-extern "C" int rma_scanner_set_efn2data( rma_scanner_t *sc, const rma_efn2data_t *efn2, char *err, size_t errlen )
-{
-	HIPCHK( hipSetDevice( sc->device ) );
-	if( sc->d_efn2 == nullptr )
-		HIPCHK( hipMalloc( &sc->d_efn2, sizeof( rma_efn2data_t ) ) );
-	HIPCHK( hipMemcpy( sc->d_efn2, efn2, sizeof( rma_efn2data_t ), hipMemcpyHostToDevice ) );
-	return 0;
-}
-
-extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
-{
-	if( sc == nullptr )
-		return;
-	if( sc->d_prog == nullptr && sc->stream == nullptr ){	// (refused before anything was set up on a device)
-		delete sc;
-		return;
-	}
-	( void )hipSetDevice( sc->device );
-	( void )hipFree( sc->d_prog );
-	( void )hipFree( sc->d_efn2 );
-	if( sc->h_raw != nullptr )
-		( void )hipHostFree( sc->h_raw );
-	if( sc->h_ctr != nullptr )
-		( void )hipHostFree( sc->h_ctr );
-	sc->dsort.release();
-	( void )hipFree( sc->d_t16 );
-	( void )hipFree( sc->d_tlkey );
-	( void )hipFree( sc->d_loginc );
-	( void )hipFree( sc->d_hits );
-	( void )hipFree( sc->d_counters );
-	( void )hipFree( sc->d_spill );
-	( void )hipFree( sc->d_pool );
-	for( int i = 0; i < 4; i++ )
-		if( sc->ev[ i ] )
-			( void )hipEventDestroy( sc->ev[ i ] );
-	if( sc->stream )
-		( void )hipStreamDestroy( sc->stream );
-	delete sc;
-}
-
-// Upload n packed entries: codes/amask hold n_code_words/n_mask_words words, base_off[] are
-// offsets in bases (multiples of 32) relative to the first word of the arrays.
-static int db_upload( rma_scanner_t *sc, const uint32_t *codes, size_t n_code_words, const uint32_t *amask,
-	size_t n_mask_words, const int64_t *base_off, const int32_t *slen, int32_t n, rma_db_t **out, char *err, size_t errlen,
-	const int32_t *pos_lo = nullptr, const int32_t *pos_hi = nullptr )
-{
-	if( pos_lo != nullptr )
-		for( int i = 0; i < n; i++ )
-			if( pos_lo[ i ] < 0 || pos_hi[ i ] < pos_lo[ i ] ){
-				snprintf( err, errlen, "entry %d: start positions [%d, %d) are not a range", i, pos_lo[ i ], pos_hi[ i ] );
-				return 1;
-			}
-	rma_db	*db = new rma_db;
-	db->sc = sc;
-	db->device = sc->device;
-	db->n_seq = n;
-	// every early return below frees what has been allocated so far
-	struct DbGuard { rma_db *p; ~DbGuard(){ if( p ) rma_db_destroy( p ); } }	guard{ db };
-	db->total_bases = 0;
-	db->strands = sc->prog.chk_both_strs ? 2 : 1;
-	std::vector<int64_t>	tile_start( size_t( n ) + 1, 0 );
-	// Launch shape.  Long entries: the scanner's tile, one per workgroup pass.  A database of
-	// many short entries (GenBank divisions, transcript sets) never fills such a tile, and a
-	// few dozen queue items cannot occupy 256 lanes: it gets small tiles in groups of
-	// SHORT_GROUP per workgroup pass (rma_search_kernel<.., G>), if the descriptor is lean and
-	// the group fits the LDS budget.
-	db->tile_t = sc->tile_t;
-	db->qcap = sc->qcap;
-	db->group = 1;
-	{
-		int64_t	tot = 0;
-		for( int i = 0; i < n; i++ ){
-			tot += slen[ i ];
-			db->max_slen = std::max( db->max_slen, slen[ i ] );
-		}
-		bool	grouped = n >= 64 && tot / n < SHORT_ENTRY_MEAN && !getenv( "RNAMOTIF_TILE" );
-		if( const char *force = getenv( "RNAMOTIF_SHORT" ) )	// "0" never, "1" always (tests)
-			grouped = force[ 0 ] == '1';
-		if( grouped && sc->dprog.lean_ok ){
-			const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64 - SHORT_GROUP * 32;
-			// (tiles of 1024 positions measured slower than of 768 where both fit: mp.ends 1.56 / 1.40 ms)
-			for( int t = 768; t >= 256; t -= 256 ){
-				int	q = 256;	// LDS goes to the slots; what a group queues beyond this spills
-				if( const char *qq = getenv( "RNAMOTIF_QCAP" ) )	// tests: force the overflow path
-					q = std::max( 64, atoi( qq ) );
-				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, true, q, SHORT_GROUP ) <= budget ){
-					db->tile_t = t;
-					db->qcap = q;
-					db->group = SHORT_GROUP;
-					break;
-				}
-			}
-		}
-	}
-	const int	T = db->tile_t;
-	for( int i = 0; i < n; i++ ){
-		int64_t	nsz = int64_t( slen[ i ] ) - sc->prog.dminlen + 1;	// start positions of a strand
-		if( pos_lo != nullptr ){
-			// this database answers for a slice of the entry's start positions only
-			db->total_bases += std::max<int64_t>( 0, std::min<int64_t>( pos_hi[ i ], slen[ i ] ) - pos_lo[ i ] );
-			nsz = std::min<int64_t>( nsz, pos_hi[ i ] ) - pos_lo[ i ];
-		}else
-			db->total_bases += slen[ i ];
-		int64_t	nt = nsz > 0 ? ( nsz + T - 1 ) / T : 0;
-		tile_start[ i + 1 ] = tile_start[ i ] + nt * db->strands;
-	}
-	db->n_tiles = tile_start[ n ];
-	HIPCHK( hipSetDevice( sc->device ) );
-	size_t	nc = std::max<size_t>( n_code_words, 1 ), na = std::max<size_t>( n_mask_words, 1 );
-	HIPCHK( hipMalloc( &db->d_codes, nc * sizeof( uint32_t ) ) );
-	HIPCHK( hipMalloc( &db->d_amask, na * sizeof( uint32_t ) ) );
-	HIPCHK( hipMalloc( &db->d_base_off, std::max<size_t>( n, 1 ) * sizeof( int64_t ) ) );
-	HIPCHK( hipMalloc( &db->d_slen, std::max<size_t>( n, 1 ) * sizeof( int32_t ) ) );
-	HIPCHK( hipMalloc( &db->d_tile_start, ( size_t( n ) + 1 ) * sizeof( int64_t ) ) );
-	if( n_code_words > 0 ){
-		HIPCHK( hipMemcpy( db->d_codes, codes, n_code_words * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
-		HIPCHK( hipMemcpy( db->d_amask, amask, n_mask_words * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
-	}
-	if( n > 0 ){
-		HIPCHK( hipMemcpy( db->d_base_off, base_off, size_t( n ) * sizeof( int64_t ), hipMemcpyHostToDevice ) );
-		HIPCHK( hipMemcpy( db->d_slen, slen, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
-	}
-	HIPCHK( hipMemcpy( db->d_tile_start, tile_start.data(), tile_start.size() * sizeof( int64_t ), hipMemcpyHostToDevice ) );
-	{
-		std::vector<int32_t>	tile_seq( size_t( std::max<int64_t>( db->n_tiles, 1 ) ) );
-		for( int i = 0; i < n; i++ )
-			for( int64_t t = tile_start[ i ]; t < tile_start[ i + 1 ]; t++ )
-				tile_seq[ size_t( t ) ] = i;
-		HIPCHK( hipMalloc( &db->d_tile_seq, tile_seq.size() * sizeof( int32_t ) ) );
-		HIPCHK( hipMemcpy( db->d_tile_seq, tile_seq.data(), tile_seq.size() * sizeof( int32_t ), hipMemcpyHostToDevice ) );
-	}
-	if( pos_lo != nullptr && n > 0 ){
-		HIPCHK( hipMalloc( &db->d_pos_lo, size_t( n ) * sizeof( int32_t ) ) );
-		HIPCHK( hipMalloc( &db->d_pos_hi, size_t( n ) * sizeof( int32_t ) ) );
-		HIPCHK( hipMemcpy( db->d_pos_lo, pos_lo, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
-		HIPCHK( hipMemcpy( db->d_pos_hi, pos_hi, size_t( n ) * sizeof( int32_t ), hipMemcpyHostToDevice ) );
-	}
-	guard.p = nullptr;
-	*out = db;
-	return 0;
-}
-
-extern "C" int rma_db_create_ranges( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens,
-	const int32_t *pos_lo, const int32_t *pos_hi, int32_t n, rma_db_t **out, char *err, size_t errlen )
-{
-	*out = nullptr;
-	rma::PackedDb	pk;
-	for( int i = 0; i < n; i++ )
-		pk.add( seqs[ i ], slens[ i ] < 0 ? 0 : slens[ i ] );
-	return db_upload( sc, pk.codes.data(), pk.codes.size(), pk.amask.data(), pk.amask.size(),
-		pk.base_off.data(), pk.slen.data(), n, out, err, errlen, pos_lo, pos_hi );
-}
-
-extern "C" int rma_db_create( rma_scanner_t *sc, const char *const *seqs, const int32_t *slens, int32_t n,
-	rma_db_t **out, char *err, size_t errlen )
-{
-	*out = nullptr;
-	rma::PackedDb	pk;
-	for( int i = 0; i < n; i++ )
-		pk.add( seqs[ i ], slens[ i ] < 0 ? 0 : slens[ i ] );
-	return db_upload( sc, pk.codes.data(), pk.codes.size(), pk.amask.data(), pk.amask.size(),
-		pk.base_off.data(), pk.slen.data(), n, out, err, errlen );
-}
-
-const rma::PackFile *rma_pack_file( const rma_pack_t *pk );	// rm_capi.cpp
-
-extern "C" int rma_db_create_packed( rma_scanner_t *sc, const rma_pack_t *pack, int32_t first, int32_t count,
-	rma_db_t **out, char *err, size_t errlen )
-{
-	*out = nullptr;
-	const rma::PackFile	&pf = *rma_pack_file( pack );
-	if( first < 0 || count < 0 || first + count > pf.count() ){
-		snprintf( err, errlen, "entries [%d, %d) are outside the packed database (%d entries)", first, first + count, pf.count() );
-		return 1;
-	}
-	if( count == 0 )
-		return db_upload( sc, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, out, err, errlen );
-	const int64_t	b0 = pf.base_off[ first ];
-	const int	last = first + count - 1;
-	const int64_t	b1 = pf.base_off[ last ] + ( ( int64_t( pf.slen[ last ] ) + 31 ) / 32 ) * 32;
-	std::vector<int64_t>	rel;
-	rel.resize( size_t( count ) );
-	for( int i = 0; i < count; i++ )
-		rel[ i ] = pf.base_off[ first + i ] - b0;
-	return db_upload( sc, pf.codes.data() + b0 / 16, size_t( ( b1 - b0 ) / 16 ), pf.amask.data() + b0 / 32,
-		size_t( ( b1 - b0 ) / 32 ), rel.data(), pf.slen.data() + first, count, out, err, errlen );
-}
-
-extern "C" int rma_db_create_packed_ranges( rma_scanner_t *sc, const rma_pack_t *pack, const int32_t *entry,
-	const int32_t *pos_lo, const int32_t *pos_hi, int32_t n, rma_db_t **out, char *err, size_t errlen )
-{
-	*out = nullptr;
-	const rma::PackFile	&pf = *rma_pack_file( pack );
-	// the chosen entries side by side (every entry starts on a 32-base boundary: whole words)
-	std::vector<uint32_t>	codes, amask;
-	std::vector<int64_t>	rel( size_t( std::max( n, 0 ) ) );
-	std::vector<int32_t>	slen( size_t( std::max( n, 0 ) ) );
-	for( int i = 0; i < n; i++ ){
-		const int	e = entry[ i ];
-		if( e < 0 || e >= pf.count() ){
-			snprintf( err, errlen, "entry %d is outside the packed database (%d entries)", e, pf.count() );
-			return 1;
-		}
-		const int64_t	w1 = pf.base_off[ e ] / 32, nw1 = ( int64_t( pf.slen[ e ] ) + 31 ) / 32;
-		rel[ i ] = int64_t( amask.size() ) * 32;
-		slen[ i ] = pf.slen[ e ];
-		codes.insert( codes.end(), pf.codes.begin() + 2 * w1, pf.codes.begin() + 2 * ( w1 + nw1 ) );
-		amask.insert( amask.end(), pf.amask.begin() + w1, pf.amask.begin() + w1 + nw1 );
-	}
-	return db_upload( sc, codes.data(), codes.size(), amask.data(), amask.size(), rel.data(), slen.data(), n, out, err, errlen,
-		pos_lo, pos_hi );
-}
-
-extern "C" void rma_db_destroy( rma_db_t *db )
-{
-	if( db == nullptr )
-		return;
-	( void )hipSetDevice( db->device );
-	( void )hipFree( db->d_codes );
-	( void )hipFree( db->d_amask );
-	( void )hipFree( db->d_base_off );
-	( void )hipFree( db->d_slen );
-	( void )hipFree( db->d_tile_start );
-	( void )hipFree( db->d_tile_seq );
-	( void )hipFree( db->d_pos_lo );
-	( void )hipFree( db->d_pos_hi );
-	delete db;
-}
-
-extern "C" int64_t rma_db_bases( const rma_db_t *db ) { return db->total_bases; }
-
-static DbView view_of( const rma_scanner *sc, const rma_db *db )
-{
-	DbView	v;
-	v.codes = db->d_codes;
-	v.amask = db->d_amask;
-	v.base_off = db->d_base_off;
-	v.slen = db->d_slen;
-	v.tile_start = db->d_tile_start;
-	v.tile_seq = db->d_tile_seq;
-	v.pos_lo = db->d_pos_lo;
-	v.pos_hi = db->d_pos_hi;
-	v.n_seq = db->n_seq;
-	v.strands = db->strands;
-	v.tile_t = db->tile_t;
-	v.n_tiles = db->n_tiles;
-	return v;
-}
-
-// wait = false: the efn kernel is left running on the scanner's stream (rma_scan() queues the ordering
-// and the copy back behind it and waits once)
-static int scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
-	float *efn_ms, char *err, size_t errlen, bool wait )
-{
-	constexpr int	BLOCK = 256;
-	HIPCHK( hipSetDevice( sc->device ) );
-	*n_hits = 0;
-	if( search_ms ) *search_ms = 0;
-	if( efn_ms ) *efn_ms = 0;
-	if( db->sc != sc ){
-		snprintf( err, errlen, "the database was created for another scanner (tiles are laid out per scanner)" );
-		return 1;
-	}
-	if( sc->need_efn2 && sc->d_efn2 == nullptr ){
-		snprintf( err, errlen, "the program has efn2() call sites but rma_scanner_set_efn2data() was not called" );
-		return 1;
-	}
-	if( db->n_tiles == 0 )
-		return 0;
-	DbView	v = view_of( sc, db );
-	const rmd_program_t	&dp = sc->dprog;
-	const int	dbg = getenv( "RNAMOTIF_DBG" ) ? atoi( getenv( "RNAMOTIF_DBG" ) ) : 0;
-	const bool	lean = dp.lean_ok && !( dbg & 16 );
-	const bool	grouped = lean && db->group > 1;
-	int	tile_bytes = db->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	size_t	lds = search_lds_bytes( sc->prog_bytes, dp, db->tile_t, lean, db->qcap, grouped ? SHORT_GROUP : 1 );
-	if( lds > 150 * 1024 ){
-		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, lds );
-		return 1;
-	}
-	// the kernel instance: lean (one tile or a group of small ones per pass), or the general one
-	// compiled for the kinds of element the descriptor has
-	int	kinds = 0;
-	for( int k = 0; k < dp.n_searches; k++ ){
-		const rmd_elem_t	&e = dp.elems[ dp.searches[ k ] ];
-		if( e.type == RMA_T_H5 && !e.proper )
-			kinds |= RMD_KIND_PK;
-		if( e.type == RMA_T_P5 || e.type == RMA_T_T1 || e.type == RMA_T_Q1 )
-			kinds |= RMD_KIND_TQ;
-	}
-	// the pooled lean instance (see the kernel): when the window of an item, four bits a base, fits the
-	// column a lane gets of the tile's place in LDS
-	bool	pooled = false;
-	if( lean && !grouped ){
-		const int	n_dw = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;
-		const size_t	room = size_t( ( tile_bytes + 15 ) & ~15 ) + size_t( 6 ) * ( ( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
-		pooled = n_dw <= 32 && size_t( n_dw ) * BLOCK * sizeof( uint32_t ) <= room;
-		if( const char *pl = getenv( "RNAMOTIF_POOL" ) )	// "0": pass B tile by tile (tests, profiles/pool_matrix.py)
-			pooled = pooled && atoi( pl ) != 0;
-	}
-	if( pooled ){
-		if( const char *pm = getenv( "RNAMOTIF_POOL_MIN" ) )
-			sc->pool_min = std::max( 1, atoi( pm ) );
-		const int	cap = sc->pool_min + db->qcap + sc->spill_cap;
-		if( cap > sc->pool_cap ){
-			( void )hipFree( sc->d_pool );
-			sc->d_pool = nullptr;
-			sc->pool_cap = 0;
-			HIPCHK( hipMalloc( &sc->d_pool, size_t( sc->grid_blocks ) * cap * 3 * sizeof( unsigned ) ) );
-			sc->pool_cap = cap;
-		}
-	}
-	typedef void	( *kernel_t )( const rmd_program_t *, int, int, DbView, HitBuf, int, int );
-	const kernel_t	kernel = pooled ? &rma_search_kernel<BLOCK, true, 1, 0, true> :
-		grouped ? &rma_search_kernel<BLOCK, true, SHORT_GROUP> : lean ? &rma_search_kernel<BLOCK, true, 1> :
-		kinds == 0 ? &rma_search_kernel<BLOCK, false, 1, 0> : kinds == RMD_KIND_PK ? &rma_search_kernel<BLOCK, false, 1, RMD_KIND_PK> :
-		kinds == RMD_KIND_TQ ? &rma_search_kernel<BLOCK, false, 1, RMD_KIND_TQ> : &rma_search_kernel<BLOCK, false, 1, RMD_KIND_PK | RMD_KIND_TQ>;
-	HIPCHK( hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t	n_units = grouped ? ( db->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : db->n_tiles;
-	int	grid = int( std::min<int64_t>( n_units, sc->grid_blocks ) );
-	unsigned long long	count = 0;
-	for( int attempt = 0; attempt < 4; attempt++ ){
-		HIPCHK( hipMemsetAsync( sc->d_counters, 0, 96 * sizeof( unsigned long long ), sc->stream ) );
-		HitBuf	hb{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap, sc->d_pool, sc->pool_cap, sc->pool_min,
-			getenv( "RNAMOTIF_POOL_REFILL" ) ? atoi( getenv( "RNAMOTIF_POOL_REFILL" ) ) : 48 };
-		HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
-		hipLaunchKernelGGL( kernel, dim3( grid ), dim3( BLOCK ), lds, sc->stream,
-			sc->d_prog, sc->prog_bytes, db->qcap, v, hb, tile_bytes, dbg );
-		HIPCHK( hipGetLastError() );
-		HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
-		// [0] candidates, [3] queue overflow of the general instance: one copy, one wait
-		HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->d_counters, 4 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, sc->stream ) );
-		HIPCHK( hipStreamSynchronize( sc->stream ) );
-		count = sc->h_ctr[ 0 ];
-		if( getenv( "RNAMOTIF_DBG" ) ){
-			unsigned long long	q = 0;
-			( void )hipMemcpy( &q, sc->d_counters + 2, sizeof( q ), hipMemcpyDeviceToHost );
-			fprintf( stderr, "[dbg] queued items: %llu, candidates %llu (tile %d x %d, queue %d, LDS %zu, %lld tiles)\n", q, count,
-				db->tile_t, grouped ? db->group : 1, db->qcap, lds, ( long long )db->n_tiles );
-			if( dbg & 32 ){
-				unsigned long long	ph[ 6 ];
-				( void )hipMemcpy( ph, sc->d_counters + 4, sizeof( ph ), hipMemcpyDeviceToHost );
-				double	tot = 0;
-				for( int i = 0; i < 6; i++ )
-					tot += double( ph[ i ] );
-				unsigned long long	lv[ 64 ];
-				( void )hipMemcpy( lv, sc->d_counters + 16, sizeof( lv ), hipMemcpyDeviceToHost );
-				if( lean )
-					fprintf( stderr, "[dbg] pass B: %llu pop rounds of %.1f lanes, %llu steps of %.1f lanes; wave cycles popping %.1f%%, stepping %.1f%%\n",
-						lv[ 0 ], lv[ 0 ] ? double( lv[ 1 ] ) / lv[ 0 ] : 0.0, lv[ 2 ], lv[ 2 ] ? double( lv[ 3 ] ) / lv[ 2 ] : 0.0,
-						100.0 * lv[ 4 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ), 100.0 * lv[ 5 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ) );
-				for( int kk = 0; kk < dp.n_searches && kk < 32 && !lean; kk++ )
-					fprintf( stderr, "[dbg] level %2d (element %2d, type %d): %llu wave rounds, %.1f lanes each\n", kk, dp.searches[ kk ],
-						dp.elems[ dp.searches[ kk ] ].type, lv[ 2 * kk ], lv[ 2 * kk ] ? double( lv[ 2 * kk + 1 ] ) / lv[ 2 * kk ] : 0.0 );
-				fprintf( stderr, "[dbg] wave cycles: decode %.1f%%, literal %.1f%%, rows %.1f%%, pre-filter %.1f%%, search %.1f%%, waiting %.1f%%\n",
-					100 * ph[ 0 ] / tot, 100 * ph[ 1 ] / tot, 100 * ph[ 2 ] / tot, 100 * ph[ 3 ] / tot, 100 * ph[ 4 ] / tot, 100 * ph[ 5 ] / tot );
-			}
-		}
-		if( !lean ){
-			// the general instance does not search queue overflow in place: a larger spill area, and again
-			const unsigned long long	need = sc->h_ctr[ 3 ];
-			if( need > 0 ){
-				if( attempt == 3 ){
-					snprintf( err, errlen, "work queue overflow after regrow (%llu items in a tile)", need );
-					return 1;
-				}
-				( void )hipFree( sc->d_spill );
-				sc->d_spill = nullptr;
-				sc->spill_cap = int( need ) + 1024;
-				HIPCHK( hipMalloc( &sc->d_spill, size_t( sc->grid_blocks ) * sc->spill_cap * sizeof( unsigned ) ) );
-				continue;
-			}
-		}
-		if( int64_t( count ) <= sc->hit_cap )
-			break;
-		if( attempt == 3 ){
-			snprintf( err, errlen, "hit buffer overflow after regrow (%llu candidates)", count );
-			return 1;
-		}
-		// count-then-emit: the first pass told us how many records there are
-		( void )hipFree( sc->d_hits );
-		sc->d_hits = nullptr;
-		sc->hit_cap = int64_t( count ) + 1024;
-		HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * dp.hit_stride * sizeof( int32_t ) ) );
-	}
-	if( search_ms )
-		HIPCHK( hipEventElapsedTime( search_ms, sc->ev[ 0 ], sc->ev[ 1 ] ) );
-	*n_hits = int64_t( count );
-	if( ( sc->have_efn || sc->d_efn2 != nullptr ) && dp.n_efn > 0 && count > 0 ){
-		constexpr int	EB = EFN_BLOCK;
-		// one workgroup per CU at most (its LDS), each striding over the candidates
-		const int64_t	blocks = std::min<int64_t>( ( int64_t( count ) + EB - 1 ) / EB, sc->grid_blocks / 8 );
-		HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
-		hipLaunchKernelGGL( rma_efn_kernel<EB>, dim3( unsigned( blocks ) ), dim3( EB ), 0, sc->stream,
-			sc->d_prog, v, sc->d_hits, ( long long )count, sc->have_efn ? sc->d_t16 : nullptr, sc->d_tlkey, sc->d_loginc,
-			sc->d_efn2 );
-		HIPCHK( hipGetLastError() );
-		HIPCHK( hipEventRecord( sc->ev[ 3 ], sc->stream ) );
-		if( wait || efn_ms )
-			HIPCHK( hipStreamSynchronize( sc->stream ) );
-		if( efn_ms )
-			HIPCHK( hipEventElapsedTime( efn_ms, sc->ev[ 2 ], sc->ev[ 3 ] ) );
-	}
-	return 0;
-}
-
-extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
-	float *efn_ms, char *err, size_t errlen )
-{
-	return scan_device( sc, db, n_hits, search_ms, efn_ms, err, errlen, true );
-}
-
-extern "C" int rma_scan( rma_scanner_t *sc, const rma_db_t *db, const int32_t **hits, int64_t *n_hits,
-	char *err, size_t errlen )
-{
-	*hits = nullptr;
-	int64_t	n = 0;
-	const bool	timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
-	auto	t0 = std::chrono::steady_clock::now();
-	auto lap = [&]( const char *what ){
-		if( timing ){
-			auto	t1 = std::chrono::steady_clock::now();
-			fprintf( stderr, "[timing] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
-			t0 = t1;
-		}
-	};
-	if( scan_device( sc, db, &n, nullptr, nullptr, err, errlen, false ) )
-		return 1;
-	lap( "search" );
-	*n_hits = n;
-	if( n == 0 )
-		return 0;
-	const int	stride = sc->dprog.hit_stride;
-	// pinned staging buffer: the copy back is a single DMA
-	const size_t	words = size_t( n ) * stride;
-	if( words > sc->h_raw_cap ){
-		if( sc->h_raw != nullptr )
-			( void )hipHostFree( sc->h_raw );
-		sc->h_raw = nullptr;
-		sc->h_raw_cap = 0;
-		HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_raw ), words * 2 * sizeof( int32_t ), hipHostMallocDefault ) );
-		sc->h_raw_cap = words * 2;
-	}
-	// Reference order -- (entry, strand, start, rank, order), order word renumbered -- on the device,
-	// behind the efn kernel on the same stream: what comes back is the final stream (rm_hitsort_dev.h).
-	// Header words that do not fit the 64-bit key (or RNAMOTIF_HOSTSORT=1): the host's sort_hits().
-	const bool	host_sort = getenv( "RNAMOTIF_HOSTSORT" ) != nullptr && atoi( getenv( "RNAMOTIF_HOSTSORT" ) ) != 0;
-	bool	on_device = false;
-	if( !host_sort && n >= 2 ){
-		auto	bits_of = []( unsigned x ){ int b = 0; while( x ){ b++; x >>= 1; } return b; };
-		if( sc->dsort.reserve( sc->hit_cap, stride ) == hipSuccess &&
-			sc->dsort.run( sc->d_hits, n, bits_of( unsigned( db->n_seq > 0 ? db->n_seq - 1 : 0 ) ), bits_of( unsigned( db->max_slen ) ),
-				bits_of( unsigned( sc->dprog.w_winsize ) ), sc->stream ) == hipSuccess ){
-			int	flag = 1;
-			HIPCHK( hipMemcpyAsync( sc->h_raw, sc->dsort.d_out, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
-			HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->dsort.d_flag, sizeof( int ), hipMemcpyDeviceToHost, sc->stream ) );
-			HIPCHK( hipStreamSynchronize( sc->stream ) );
-			memcpy( &flag, sc->h_ctr, sizeof( flag ) );
-			on_device = flag == 0;
-			if( !on_device && sc->dsort.w_ord < 31 )
-				sc->dsort.w_ord = 31;	// (order words above 255: room for them from now on, if the other fields leave it)
-		}else
-			( void )hipGetLastError();
-	}
-	if( on_device ){
-		lap( "ordered" );
-		*hits = sc->h_raw;
-		return 0;
-	}
-	HIPCHK( hipMemcpyAsync( sc->h_raw, sc->d_hits, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
-	HIPCHK( hipStreamSynchronize( sc->stream ) );
-	lap( "copy back" );
-	sc->h_sorted.resize( words );
-	rma::sort_hits( sc->h_raw, n, stride, sc->h_sorted.data(), sc->keys, sc->keys_tmp );
-	lap( "ordering" );
-	*hits = sc->h_sorted.data();
-	return 0;
+// ---------------------------------------------------------------- launchers
+// One per translation unit (rm_scan_inst_*.hip): the instance's dynamic LDS limit and its launch.
+#define RMK_DEFINE_LAUNCHER( name_, LEAN_, G_, KINDS_, POOL_ ) \
+hipError_t name_( int grid, size_t lds, hipStream_t s, const rmk_search_args &a ) \
+{ \
+	auto	kernel = &rma_search_kernel<SEARCH_BLOCK, LEAN_, G_, KINDS_, POOL_>; \
+	hipError_t	e = hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ); \
+	if( e != hipSuccess ) \
+		return e; \
+	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( SEARCH_BLOCK ), lds, s, \
+		a.d_prog, a.prog_bytes, a.qcap, a.db, a.hb, a.tile_bytes, a.dbg ); \
+	return hipGetLastError(); \
 }

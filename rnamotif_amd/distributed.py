@@ -136,6 +136,32 @@ def gather_hits(local_hits: np.ndarray, global_index: Sequence[int], stride: int
     return np.zeros((0, stride), dtype=np.int32) if concat else []
 
 
+class NativeGather:
+    """rma_gather_hits() of the C ABI (rnamotif_amd/csrc/rm_gather.cpp): the records of every rank's
+    last scan travel from HBM to HBM over RCCL -- an all-gather of the counts and one grouped
+    send/receive, no padding, no host hop -- and reach rank 0's host in one copy.  torch.distributed
+    only hands rank 0's communicator id to the other ranks (one 128-byte broadcast at start-up)."""
+
+    def __init__(self, rank: int, world: int, device_index: int, coll_device=None):
+        import torch
+        import torch.distributed as dist
+        from . import Comm
+
+        def bcast(buf: bytearray) -> None:
+            t = torch.tensor(list(buf), dtype=torch.uint8, device=coll_device if coll_device is not None else torch.device("cpu"))
+            dist.broadcast(t, src=0)
+            buf[:] = bytes(t.cpu().tolist())
+
+        self.comm = Comm(rank, world, device_index, broadcast=bcast)
+
+    def gather(self, scanner, global_index: Sequence[int], root: int = 0):
+        """(records on root -- rank by rank, each part in order -- else empty; counts per rank)"""
+        return self.comm.gather(scanner, global_index, root)
+
+    def close(self) -> None:
+        self.comm.close()
+
+
 def sort_hits(allh: np.ndarray) -> np.ndarray:
     """Records by (seq, comp, szero, rank, order) = the reference's output order: the library's
     rma_sort_hits() (host code, the same sort a single scan ends with)."""

@@ -7,10 +7,14 @@ One process per GPU.  Every rank reads the database with the library's own reade
 (rma_pack_read: what rnamotif reads, -fmt and -N included), takes its share of the
 entries -- entries longer than a share are cut into slices of start positions -- and
 uploads only that (rma_db_create_packed_ranges); the candidate records travel to rank 0
-in one variable-length gather over RCCL; rank 0 runs the score program and prints, in
-the reference's order, exactly what `rnamotif` prints.  The
+in one variable-length gather over RCCL (rma_gather_hits of the C ABI: from HBM to HBM;
+or torch.distributed's gather where that cannot be set up); rank 0 runs the score program
+and prints, in the reference's order, exactly what `rnamotif` prints.  The
 reference's own parallel driver hands whole files to MPI workers and collects
 their text (/root/reference/src/mrnamotif.c:733,910-917).
+
+Environment: RNAMOTIF_DIST_BACKEND (default nccl = RCCL; gloo: several ranks on one GPU, as the
+tests run it), RNAMOTIF_DEVICE (GPU ordinal instead of LOCAL_RANK), RNAMOTIF_GATHER=torch.
 """
 from __future__ import annotations
 
@@ -52,17 +56,27 @@ def _read_database(argv: Sequence[str], files: Sequence[str]) -> "R.Pack":
     return R.Pack.read(list(files), fmt=_option(argv, "-fmt"), maxslen=int(n) if n else 0)
 
 
-def _scan_shard(descr, pack, entries, ranges, local_rank: int) -> np.ndarray:
+def _device_index(local_rank: int) -> int:
+    return int(os.environ.get("RNAMOTIF_DEVICE", local_rank))
+
+
+def _scan_shard(descr, pack, entries, ranges, local_rank: int, on_device: bool = False):
     """This rank's share on its GPU: its entries of the packed database, each with its range of
-    start positions, straight into HBM (rma_db_create_packed_ranges + rma_scan)."""
-    if not entries:
+    start positions, straight into HBM (rma_db_create_packed_ranges + rma_scan).  on_device: the
+    ordered records stay in HBM for the native gather and the scanner is returned with them."""
+    if not entries and not on_device:
         return np.zeros((0, descr.hit_stride), np.int32)
-    sc = R.Scanner(descr, device=local_rank)
-    return sc.scan(sc.database_from_pack(pack, entries=entries, ranges=ranges))
+    sc = R.Scanner(descr, device=_device_index(local_rank))
+    db = sc.database_from_pack(pack, entries=entries, ranges=ranges)
+    if not on_device:
+        return sc.scan(db)
+    sc.scan_begin(db)
+    sc.scan_end_on_device()
+    return sc, db
 
 
 def _init_process_group(world: int, local_rank: int):
-    """One process per GPU over RCCL; returns the device the gather uses."""
+    """One process per GPU over RCCL; returns the device the collectives' tensors live on."""
     import datetime
     import torch
     import torch.distributed as dist
@@ -71,10 +85,28 @@ def _init_process_group(world: int, local_rank: int):
     if world == 1:
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("RNAMOTIF_DIST_BACKEND", "nccl")
+    idx = _device_index(local_rank)
+    torch.cuda.set_device(idx)
+    if backend != "nccl":
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=10))
+        return torch.device("cpu")
+    dev = torch.device("cuda", idx)
     dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
     return dev
+
+
+def _native_gather(world: int, rank: int, local_rank: int, dev):
+    """The C ABI's gather when RCCL carries the job (every rank agrees), else None."""
+    if world == 1 or dev is None or dev.type != "cuda" or os.environ.get("RNAMOTIF_GATHER", "native") != "native":
+        return None
+    from rnamotif_amd.distributed import NativeGather
+    ng = None
+    try:
+        ng = NativeGather(rank, world, _device_index(local_rank), dev)
+    except Exception as e:      # noqa: BLE001 -- the same exchange over torch.distributed then
+        sys.stderr.write(f"mrnamotif (rank {rank}): native gather not available ({e})\n")
+    return ng if all_ok(ng is not None, dev) else None
 
 
 def run(argv: Sequence[str], out_path: str = "-") -> int:
@@ -87,7 +119,8 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
     rank = dist.get_rank() if world > 1 else 0
 
     # a rank that cannot do its part says so before the gather: nobody is left waiting
-    failure, descr, pack, hits, mine = None, None, None, None, []
+    failure, descr, pack, hits, mine, held = None, None, None, None, [], None
+    native = _native_gather(world, rank, local_rank, dev)
     try:
         descr = R.Descriptor(list(argv))
         files = database_files(argv)
@@ -98,7 +131,10 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
             mx = "UNBND" if descr.maxlen == 0x7fffffff else str(descr.maxlen)
             sys.stderr.write(f"{_option(argv, '-descr')}: complete descr length: min/max = {descr.minlen}/{mx}\n")
         mine = partition_ranges(pack.lengths(), world)[rank]
-        hits = _scan_shard(descr, pack, [i for i, _, _ in mine], [(lo, hi) for _, lo, hi in mine], local_rank)
+        if native is not None:
+            held = _scan_shard(descr, pack, [i for i, _, _ in mine], [(lo, hi) for _, lo, hi in mine], local_rank, on_device=True)
+        else:
+            hits = _scan_shard(descr, pack, [i for i, _, _ in mine], [(lo, hi) for _, lo, hi in mine], local_rank)
     except Exception as e:      # noqa: BLE001 -- reported below, on every rank
         failure = e
     if not all_ok(failure is None, dev):
@@ -107,7 +143,12 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
         if world > 1:
             dist.destroy_process_group()
         return 1
-    if world > 1:
+    if native is not None:
+        # from HBM to HBM; the ranks' entries interleave (greedy partition), so rank 0 merges the parts
+        hits, _ = native.gather(held[0], [i for i, _, _ in mine])
+        hits = sort_hits(hits)
+        native.close()
+    elif world > 1:
         hits = gather_hits(hits, [i for i, _, _ in mine], descr.hit_stride, device=dev)
     elif hits.shape[0]:
         hits = hits.copy()

@@ -3,6 +3,8 @@ oracle and the reference's pinned outputs.  Run on the MI355X box: -m gpu."""
 import hashlib
 import os
 import subprocess
+import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -182,15 +184,8 @@ def test_search_paths_agree(built, workdir, name, dbg):
     want = oracle_scan(d, seqs)
     sc = R.Scanner(d)
     db = sc.database(seqs)
-    old = os.environ.get("RNAMOTIF_DBG")
-    os.environ["RNAMOTIF_DBG"] = str(dbg)
-    try:
-        got = sc.scan(db)
-    finally:
-        if old is None:
-            del os.environ["RNAMOTIF_DBG"]
-        else:
-            os.environ["RNAMOTIF_DBG"] = old
+    sc.set_option("dbg", dbg)          # (the environment is read once, at the scanner's creation)
+    got = sc.scan(db)
     assert np.array_equal(got, want)
 
 
@@ -211,16 +206,19 @@ def test_pooled_and_tile_by_tile_pass_b_agree(built, workdir, gbrna, name):
     want = oracle_scan(d, seqs)
     sc = R.Scanner(d)
     db = sc.database(seqs)
-    for env in ({}, {"RNAMOTIF_POOL": 0}, {"RNAMOTIF_POOL_MIN": 8, "RNAMOTIF_POOL_REFILL": 1}, {"RNAMOTIF_POOL_MIN": 100000}):
-        with _env(**env):
-            got = sc.scan(db)
-        assert got.shape == want.shape and np.array_equal(got, want), env
+    base = {"pool": -1, "pool_min": 1024, "pool_refill": 48}
+    for opts in ({}, {"pool": 0}, {"pool_min": 8, "pool_refill": 1}, {"pool_min": 100000}):
+        for k, v in dict(base, **opts).items():
+            sc.set_option(k, v)
+        got = sc.scan(db)
+        assert got.shape == want.shape and np.array_equal(got, want), opts
     # slices of start positions (what a rank of a multi-GPU job holds)
     sl = sc.database(seqs, ranges=[(0, 100_000), (10, 61), (0, 7), (20_000, 40_000), (5, 29_000)] + [(0, len(s)) for s in seqs[5:]])
     ref = None
-    for env in ({"RNAMOTIF_POOL": 0}, {}):
-        with _env(**env):
-            got = sc.scan(sl)
+    for opts in ({"pool": 0}, {}):
+        for k, v in dict(base, **opts).items():
+            sc.set_option(k, v)
+        got = sc.scan(sl)
         if ref is None:
             ref = got
         assert np.array_equal(got, ref)
@@ -305,23 +303,27 @@ def test_syn10m_cli_hit_counts(built, workdir, tmp_path_factory, name):
         assert b" ".join(first.split()) == b" ".join(SYN10M_FIRST_TRNA.split())
 
 
-@pytest.mark.parametrize("name", ["trna.efn.descr", "mp.ends.descr"])
+def _sorted_unique(h):
+    key = h[:, :5]
+    order = np.lexsort(key.T[::-1])
+    assert np.array_equal(order, np.arange(len(order))), "records are not in (seq, comp, szero, rank, order) order"
+    assert len(np.unique(key, axis=0)) == len(key)
+
+
+@pytest.mark.parametrize("name", ["trna.efn.descr", "mp.ends.descr", "pk1.descr"])
 def test_full_size_properties(built, workdir, name):
-    """BASELINE.json's headline size (100 records of 1 Mbase, the bench workload), where the
-    oracle would take minutes: properties that hold at any size.  (1) Shards add up: the two
-    halves of the database scanned separately are the whole scan.  (2) Strands mirror: the
-    reverse complement of every record gives the same candidates with the strand flag flipped
-    (offsets in a record are strand local).  (3) Sorted, no duplicates."""
+    """BASELINE.json's headline size (100 records of 1 Mbase, the bench workload; pk1.descr is
+    config 3), where the oracle would take minutes: properties that hold at any size.  (1) Shards
+    add up: the two halves of the database scanned separately are the whole scan.  (2) Strands
+    mirror: the reverse complement of every record gives the same candidates with the strand flag
+    flipped (offsets in a record are strand local).  (3) Sorted, no duplicates."""
     import rnamotif_amd as R
     d = _descr(workdir, name)
     seqs = R.synthetic_records(100)
     sc = R.Scanner(d)
     whole = sc.scan(sc.database(seqs))
     assert whole.shape[0] > 100
-    key = whole[:, :5]
-    order = np.lexsort(key.T[::-1])
-    assert np.array_equal(order, np.arange(len(order))), "records are not in (seq, comp, szero, rank, order) order"
-    assert len(np.unique(key, axis=0)) == len(key)
+    _sorted_unique(whole)
     # (1)
     a = sc.scan(sc.database(seqs[:50]))
     b = sc.scan(sc.database(seqs[50:]))
@@ -335,6 +337,72 @@ def test_full_size_properties(built, workdir, name):
     mirror[:, 1] ^= 1
     mirror = mirror[np.lexsort(mirror[:, :5].T[::-1])]
     assert np.array_equal(mirror, whole)
+
+
+def test_full_size_mixed_batch_on_one_database(built, workdir):
+    """BASELINE config 5's single-GPU form: qu+tr.descr and mp.ends.descr over ONE upload of the 100
+    Mbase database (a database belongs to a device, not to a descriptor), their kernels side by
+    side on two streams.  Same records as each descriptor alone on a database of its own; shards
+    add up; strands mirror; sorted, no duplicates."""
+    import rnamotif_amd as R
+    names = ("qu+tr.descr", "mp.ends.descr")
+    ds = [_descr(workdir, n) for n in names]
+    seqs = R.synthetic_records(100)
+    scs = [R.Scanner(d) for d in ds]
+    shared = scs[0].database(seqs)
+    for sc in scs:
+        sc.attach(shared)
+    for sc in scs:
+        sc.scan_begin(shared)
+    together = [sc.scan_end() for sc in scs]
+    tr = bytes.maketrans(b"acgt", b"tgca")
+    for d, sc, got in zip(ds, scs, together):
+        assert got.shape[0] > 100
+        _sorted_unique(got)
+        own = R.Scanner(d)
+        alone = own.scan(own.database(seqs))
+        assert np.array_equal(alone, got)
+        a = own.scan(own.database(seqs[:37]))
+        b = own.scan(own.database(seqs[37:]))
+        b[:, 0] += 37
+        assert np.array_equal(np.concatenate([a, b]), got)
+    rc = scs[0].database([s.translate(tr)[::-1] for s in seqs])
+    for sc, got in zip(scs, together):
+        mirror = sc.scan(rc)
+        mirror[:, 1] ^= 1
+        mirror = mirror[np.lexsort(mirror[:, :5].T[::-1])]
+        assert np.array_equal(mirror, got)
+
+
+def test_one_gbase_is_the_sum_of_its_slices(built, workdir):
+    """The north star's size -- trna.descr over 1000 records of 1 Mbase on one GPU, the figure
+    bench.py reports as north_star_1gbase: its records are the ten 100-record slices' records, one
+    after the other (the first slice is the headline workload), sorted, no duplicates."""
+    import rnamotif_amd as R
+    sys.path.insert(0, ROOT)
+    from bench import synthetic_slice
+    d = _descr(workdir, "trna.efn.descr")
+    sc = R.Scanner(d)
+    parts = []
+    with tempfile.TemporaryDirectory() as tmp:
+        pk = os.path.join(tmp, "g.rmpk")
+        recs = []
+        for k in range(10):
+            seqs = synthetic_slice(100 * k, 100, 1_000_000)
+            if k == 0:
+                assert seqs[:3] == R.synthetic_records(3)          # (the jump into the stream lands where the stream is)
+            h = sc.scan(sc.database(seqs))
+            h[:, 0] += 100 * k
+            parts.append(h)
+            recs += [(b"syn%04d" % (100 * k + i), b"", s) for i, s in enumerate(seqs)]
+        del seqs
+        R.Pack.write(pk, recs)
+        del recs
+        pack = R.Pack(pk)
+    whole = sc.scan(sc.database_from_pack(pack))
+    assert pack.bases == 1_000_000_000 and whole.shape[0] > 50_000
+    _sorted_unique(whole)
+    assert np.array_equal(np.concatenate(parts), whole)
 
 
 def test_start_position_ranges(built, workdir):
@@ -644,7 +712,8 @@ def test_random_descriptors_equal_oracle(built, tmp_path, seed):
     pieces = [bytes(s[a:a + int(ln)]) for a, ln in zip(range(0, n - 900, 700), rng.integers(0, 900, size=64))]
     want = oracle_scan(d, pieces)
     with _env(RNAMOTIF_SHORT="1", RNAMOTIF_QCAP=(64 if seed % 2 else None)):
-        got = sc.scan(sc.database(pieces))
+        sc2 = R.Scanner(d)             # (the launch-shape variables are read when a scanner is created)
+        got = sc2.scan(sc2.database(pieces))
     assert got.shape == want.shape, text
     assert np.array_equal(got, want), text
 
@@ -788,7 +857,8 @@ def test_random_general_descriptors_equal_oracle(built, tmp_path, seed, strict):
     pieces = [s[a:a + int(ln)] for a, ln in zip(range(0, 5000, 450), rng.integers(0, 700, size=64))]
     want = oracle_scan(d, pieces)
     with _env(RNAMOTIF_SHORT="1", RNAMOTIF_QCAP=(64 if seed % 2 else None)):
-        got = sc.scan(sc.database(pieces))
+        sc2 = R.Scanner(d)             # (the launch-shape variables are read when a scanner is created)
+        got = sc2.scan(sc2.database(pieces))
     assert got.shape == want.shape, text
     assert np.array_equal(got, want), text
 

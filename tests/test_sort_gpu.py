@@ -26,8 +26,9 @@ def test_device_order_equals_host_order(built, workdir, gbrna, name):
     sc = R.Scanner(d)
     db = sc.database(seqs)
     dev = sc.scan(db)
-    with _env(RNAMOTIF_HOSTSORT=1):
-        host = sc.scan(db)
+    sc.set_option("host_sort", 1)
+    host = sc.scan(db)
+    sc.set_option("host_sort", 0)
     assert np.array_equal(dev, host)
     assert dev.shape[0] > 1 or name == "qu+tr.descr"      # (nothing of that shape in these entries)
     again = sc.scan(db)
@@ -48,6 +49,6 @@ def test_order_words_beyond_the_key_field(built, tmp_path):
     db = sc.database(seqs)
     first = sc.scan(db)          # falls back to the host sort, widens the field
     second = sc.scan(db)         # on the device with the wide field
-    with _env(RNAMOTIF_HOSTSORT=1):
-        host = sc.scan(db)
+    sc.set_option("host_sort", 1)
+    host = sc.scan(db)
     assert np.array_equal(first, want) and np.array_equal(second, want) and np.array_equal(host, want)
