@@ -633,6 +633,308 @@ void ScoreVM::dump( FILE *fp )	// RM_dumpscore :563, dumpinst :3576
 	}
 }
 
+// ---------------------------------------------------------------- hit independence
+// A forward data-flow pass over MAIN: per instruction the variables that are definitely assigned,
+// the type every variable of interest has (the VM latches the type of an undefined variable at its
+// first assignment, do_sto score.c:2234, and converts later values to it), and the types on the
+// evaluation stack.  The stack is empty at every statement boundary (FJP and CLS reset it), so the
+// states that meet at a label differ in the variables only -- and, inside an expression, in the top
+// of the stack after && / || (joined to "unknown" when the operands' types differ).
+bool ScoreVM::hit_independent( std::string *why ) const
+{
+	auto no = [&]( const std::string &m ){ if( why ) *why = m; return false; };
+	const std::vector<Inst>	&pr = progs_[ P_MAIN ];
+	if( pr.empty() )
+		return true;
+	enum { TY_TOP = 100, TY_MARK = 101 };		// unknown; a MRK slot
+	// the variables MAIN may write
+	std::vector<const Ident *>	vars;
+	auto var_of = [&]( const void *p ) -> int {
+		for( size_t i = 0; i < vars.size(); i++ )
+			if( vars[ i ] == p )
+				return int( i );
+		return -1;
+	};
+	for( const Inst &ip : pr ){
+		if( ip.op == OP_HOLD || ip.op == OP_RLSE )
+			return no( "HOLD / RELEASE keep candidates across hits" );
+		if( ip.op == OP_FCL )
+			return no( "unimplemented instruction" );
+		if( ip.op == OP_LDA && var_of( ip.val.pval ) < 0 )
+			vars.push_back( ( const Ident * )ip.val.pval );
+	}
+	for( int p : { P_BEGIN, P_END } )
+		for( const Inst &ip : progs_[ p ] )
+			if( ip.op == OP_HOLD || ip.op == OP_RLSE )
+				return no( "HOLD / RELEASE in BEGIN or END" );
+	for( const Inst &ip : progs_[ P_END ] )
+		if( ( ip.op == OP_LOD || ip.op == OP_LDA ) && var_of( ip.val.pval ) >= 0 )
+			return no( "END uses a variable MAIN writes" );
+	if( vars.size() > 64 )
+		return no( "more than 64 variables written" );
+	const int	nv = int( vars.size() );
+	int	score_var = -1;
+	for( int i = 0; i < nv; i++ )
+		if( &vars[ i ]->val == d_.sval )
+			score_var = i;
+	struct State {
+		bool	seen = false;
+		uint64_t	da = 0;
+		std::vector<int>	vt;		// type of every variable: T_UNDEF .. T_STRING or TY_TOP
+		std::vector<int>	stk;		// T_* / TY_TOP / TY_MARK / T_IDENT + 1000 * ( var + 1 )
+	};
+	std::vector<State>	st( pr.size() + 1 );
+	std::vector<int>	work;
+	State	entry;
+	entry.seen = true;
+	entry.vt.resize( size_t( nv ) );
+	for( int i = 0; i < nv; i++ )
+		entry.vt[ i ] = vars[ i ]->type;		// (what BEGIN and the parms section left)
+	auto join_type = []( int a, int b ){ return a == b ? a : int( TY_TOP ); };
+	std::string	trouble;
+	auto merge = [&]( int pc, const State &s ){
+		if( pc < 0 || pc > int( pr.size() ) ){
+			trouble = "jump out of the program";
+			return;
+		}
+		State	&t = st[ size_t( pc ) ];
+		if( !t.seen ){
+			t = s;
+			t.seen = true;
+			work.push_back( pc );
+			return;
+		}
+		bool	changed = false;
+		const uint64_t	da = t.da & s.da;
+		if( da != t.da ){
+			t.da = da;
+			changed = true;
+		}
+		for( int i = 0; i < nv; i++ ){
+			const int	j = join_type( t.vt[ i ], s.vt[ i ] );
+			if( j != t.vt[ i ] ){
+				t.vt[ i ] = j;
+				changed = true;
+			}
+		}
+		if( t.stk.size() != s.stk.size() ){
+			trouble = "evaluation stacks of different depth meet";
+			return;
+		}
+		for( size_t i = 0; i < t.stk.size(); i++ ){
+			const int	j = join_type( t.stk[ i ], s.stk[ i ] );
+			if( j != t.stk[ i ] ){
+				if( t.stk[ i ] == TY_MARK || s.stk[ i ] == TY_MARK ){
+					trouble = "a mark meets a value";
+					return;
+				}
+				t.stk[ i ] = j;
+				changed = true;
+			}
+		}
+		if( changed )
+			work.push_back( pc );
+	};
+	merge( 0, entry );
+	int	rounds = 0;
+	while( !work.empty() && trouble.empty() ){
+		if( ++rounds > 200000 )
+			return no( "analysis does not settle" );
+		const int	pc = work.back();
+		work.pop_back();
+		if( pc >= int( pr.size() ) )
+			return no( "MAIN runs off its end" );
+		State	s = st[ size_t( pc ) ];
+		const Inst	&ip = pr[ size_t( pc ) ];
+		std::vector<int>	&k = s.stk;
+		auto need = [&]( size_t n ){
+			if( k.size() < n ){
+				trouble = "evaluation stack underflow";
+				return false;
+			}
+			for( size_t i = k.size() - n; i < k.size(); i++ )
+				if( k[ i ] == TY_MARK ){
+					trouble = "operand below a mark";
+					return false;
+				}
+			return true;
+		};
+		// a value of a builtin / element reference replaces everything from the last mark on
+		auto ret_to_mark = [&]( int ty ){
+			int	m = int( k.size() ) - 1;
+			while( m >= 0 && k[ size_t( m ) ] != TY_MARK )
+				m--;
+			if( m < 0 ){
+				trouble = "call without a mark";
+				return;
+			}
+			k.resize( size_t( m ) );
+			k.push_back( ty );
+		};
+		int	next = pc + 1, jump = -1;
+		switch( ip.op ){
+		case OP_NOOP :
+			break;
+		case OP_HALT :
+			return no( "HALT in MAIN" );
+		case OP_ACPT :
+			// the printer reads SCORE
+			if( score_var >= 0 && !( ( s.da >> score_var ) & 1 ) )
+				return no( "SCORE may reach the printer with an earlier hit's value" );
+			next = -1;
+			break;
+		case OP_RJCT :
+			next = -1;
+			break;
+		case OP_MRK :
+			k.push_back( TY_MARK );
+			break;
+		case OP_CLS :
+			k.clear();
+			break;
+		case OP_FJP :
+			if( k.empty() ){
+				trouble = "FJP on an empty stack";
+				break;
+			}
+			k.clear();
+			jump = ip.val.ival;
+			break;
+		case OP_JMP :
+			jump = ip.val.ival;
+			next = -1;
+			break;
+		case OP_LDA : {
+			const int	v = var_of( ip.val.pval );
+			k.push_back( T_IDENT + 1000 * ( v + 1 ) );
+			break;
+		}
+		case OP_LOD : {
+			const int	v = var_of( ip.val.pval );
+			if( v < 0 ){
+				const int	t = ( ( const Ident * )ip.val.pval )->type;	// never written by MAIN: as it is now
+				k.push_back( t == T_INT || t == T_FLOAT || t == T_STRING ? t : int( TY_TOP ) );
+			}else{
+				if( !( ( s.da >> v ) & 1 ) )
+					return no( "variable '" + vars[ size_t( v ) ]->name + "' may be read with an earlier hit's value" );
+				k.push_back( s.vt[ size_t( v ) ] == T_UNDEF ? int( TY_TOP ) : s.vt[ size_t( v ) ] );
+			}
+			break;
+		}
+		case OP_LDC :
+			switch( ip.val.type ){
+			case T_INT : case T_POS : k.push_back( T_INT ); break;
+			case T_FLOAT : k.push_back( T_FLOAT ); break;
+			case T_STRING : k.push_back( T_STRING ); break;
+			case T_PAIRSET : k.push_back( T_PAIRSET ); break;
+			default : k.push_back( TY_TOP ); break;
+			}
+			break;
+		case OP_STO : {
+			if( !need( 2 ) )
+				break;
+			const int	top = k.back(), tm1 = k[ k.size() - 2 ];
+			if( tm1 < 1000 || tm1 % 1000 != T_IDENT )
+				return no( "assignment to something that is not a variable" );
+			const int	v = tm1 / 1000 - 1;
+			k.pop_back();
+			int	&vt = s.vt[ size_t( v ) ];
+			if( vt == T_UNDEF ){
+				// the first assignment ever latches the type: every assignment must agree on it
+				if( top != T_INT && top != T_FLOAT && top != T_STRING )
+					return no( "type of variable '" + vars[ size_t( v ) ]->name + "' depends on which hit assigns it first" );
+				vt = top;
+			}else if( vt == TY_TOP )
+				return no( "type of variable '" + vars[ size_t( v ) ]->name + "' depends on the path taken" );
+			else if( top != T_INT && top != T_FLOAT && top != T_STRING )
+				return no( "assignment of a value of unknown type" );
+			// (do_sto leaves the slot typed like the value for int and float, like the variable otherwise;
+			// what follows an assignment reads at most its int view)
+			k.back() = vt == top ? vt : int( TY_TOP );
+			s.da |= 1ull << v;
+			break;
+		}
+		case OP_AND :
+		case OP_IOR :
+			if( !need( 1 ) )
+				break;
+			jump = ip.val.ival;		// (the normalised left operand is the value on that path)
+			break;
+		case OP_NOT :
+		case OP_NEG :
+			need( 1 );
+			break;
+		case OP_MAT :
+			if( need( 2 ) ){
+				k.pop_back();
+				k.back() = T_INT;
+			}
+			break;
+		case OP_INS :
+			ret_to_mark( T_INT );
+			break;
+		case OP_GTR : case OP_GEQ : case OP_EQU : case OP_NEQ : case OP_LEQ : case OP_LES :
+			if( need( 2 ) ){
+				k.pop_back();
+				k.back() = T_INT;
+			}
+			break;
+		case OP_ADD : case OP_SUB : case OP_MUL : case OP_DIV : case OP_MOD :
+			if( need( 2 ) ){
+				k.pop_back();		// (the left operand keeps its type, do_arith)
+				if( k.back() != T_INT && k.back() != T_FLOAT && k.back() != T_STRING )
+					k.back() = TY_TOP;
+			}
+			break;
+		case OP_I_PP : case OP_PP_I : case OP_I_MM : case OP_MM_I : {
+			if( !need( 1 ) )
+				break;
+			const int	top = k.back();
+			if( top < 1000 )
+				return no( "increment of something that is not a variable" );
+			const int	v = top / 1000 - 1;
+			if( !( ( s.da >> v ) & 1 ) )
+				return no( "variable '" + vars[ size_t( v ) ]->name + "' is counted from one hit to the next" );
+			k.back() = TY_TOP;		// (the slot keeps its identifier type in the VM)
+			break;
+		}
+		case OP_STRF :
+			if( need( 3 ) ){
+				k.pop_back();
+				k.pop_back();
+				k.back() = T_STRING;
+			}
+			break;
+		case OP_SCL :
+			switch( ip.val.ival ){
+			case SC_BITS : case SC_EFN : case SC_EFN2 :
+				ret_to_mark( T_FLOAT );
+				break;
+			case SC_SPRINTF : case SC_SUBSTR :
+				ret_to_mark( T_STRING );
+				break;
+			default :
+				ret_to_mark( T_INT );
+				break;
+			}
+			break;
+		default :
+			return no( "instruction the analysis does not know" );
+		}
+		if( !trouble.empty() )
+			break;
+		if( jump >= 0 ){
+			State	j = s;
+			merge( jump, j );
+		}
+		if( next >= 0 )
+			merge( next, s );
+	}
+	if( !trouble.empty() )
+		return no( trouble );
+	return true;
+}
+
 // ---------------------------------------------------------------- execution
 Strel *ScoreVM::xd( const Inst &ip, int idx, const char *who )
 {

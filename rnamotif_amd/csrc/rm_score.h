@@ -63,6 +63,15 @@ public:
 	// the scanner delivered for efn_calls() (1/100 kcal/mol), or nullptr.
 	int	run( int comp, int slen, const char *sbuf, Ident **h_id, const int32_t *efn_vals );
 
+	// True when no candidate's run of MAIN can see what another candidate's run left behind, so that
+	// candidates may be replayed on several VMs at once (each on a descriptor compiled for it) and
+	// their output put together in order: no HOLD / RELEASE; every variable MAIN writes is definitely
+	// assigned before MAIN -- or the printer, for SCORE -- reads it, on every path; a variable whose type
+	// the first assignment would latch (undefined after BEGIN) gets the same type from every assignment;
+	// END reads nothing MAIN writes.  Conservative: anything the analysis cannot follow says no (*why).
+	// To be called after linkscore() and after BEGIN has run.
+	bool	hit_independent( std::string *why ) const;
+
 	const std::vector<EfnCall>	&efn_calls() const { return efn_calls_; }
 	bool	has_main() const { return !progs_[ P_MAIN ].empty(); }
 	void	dump( FILE *fp );		// RM_dumpscore :563

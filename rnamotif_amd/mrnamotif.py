@@ -14,7 +14,9 @@ reference's own parallel driver hands whole files to MPI workers and collects
 their text (/root/reference/src/mrnamotif.c:733,910-917).
 
 Environment: RNAMOTIF_DIST_BACKEND (default nccl = RCCL; gloo: several ranks on one GPU, as the
-tests run it), RNAMOTIF_DEVICE (GPU ordinal instead of LOCAL_RANK), RNAMOTIF_GATHER=torch.
+tests run it), RNAMOTIF_DEVICE (GPU ordinal instead of LOCAL_RANK), RNAMOTIF_GATHER=torch,
+RNAMOTIF_OUTPUT (rank 0 writes the hits to this file instead of stdout, which a launcher's or a
+transport library's own messages may share).
 """
 from __future__ import annotations
 
@@ -165,4 +167,4 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(run(sys.argv[1:]))
+    sys.exit(run(sys.argv[1:], os.environ.get("RNAMOTIF_OUTPUT", "-")))

@@ -44,12 +44,13 @@ def test_mrnamotif_two_ranks_equal_rnamotif_on_gbrna(built, workdir, gbrna, tmp_
     want = subprocess.run([built["cli"], "-descr", name, "gbrna.111.0.fastn"], cwd=workdir, env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert want.returncode == 0 and want.stdout.count(b"\n>") > 5
-    p = _torchrun(["-m", "rnamotif_amd.mrnamotif", "-descr", name, "gbrna.111.0.fastn"], workdir)
+    out = tmp_path / "hits.txt"         # (gloo prints its own notices on stdout)
+    p = _torchrun(["-m", "rnamotif_amd.mrnamotif", "-descr", name, "gbrna.111.0.fastn"], workdir, env={"RNAMOTIF_OUTPUT": str(out)})
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    assert _stdout(p) == want.stdout
+    assert out.read_bytes() == want.stdout
 
 
-def test_mrnamotif_two_ranks_equal_rnamotif_on_syn10m(built, workdir, tmp_path_factory):
+def test_mrnamotif_two_ranks_equal_rnamotif_on_syn10m(built, workdir, tmp_path_factory, tmp_path):
     """... and over syn10M, whose ten 1 Mbase entries are cut into slices of start positions
     between the ranks (rma_db_create_packed_ranges); 630 hits, the reference's own number."""
     import rnamotif_amd as R
@@ -64,14 +65,10 @@ def test_mrnamotif_two_ranks_equal_rnamotif_on_syn10m(built, workdir, tmp_path_f
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert want.returncode == 0
     assert want.stdout.count(b"\n>") + want.stdout.startswith(b">") == pins.SYN10M["trna.efn.descr"]
-    p = _torchrun(["-m", "rnamotif_amd.mrnamotif", "-descr", "trna.efn.descr", str(fa)], workdir)
+    out = tmp_path / "hits.txt"
+    p = _torchrun(["-m", "rnamotif_amd.mrnamotif", "-descr", "trna.efn.descr", str(fa)], workdir, env={"RNAMOTIF_OUTPUT": str(out)})
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    assert _stdout(p) == want.stdout
-
-
-def _stdout(p):
-    """the ranks' stdout without gloo's own connection notice (the library prints it there)"""
-    return b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"[Gloo]"))
+    assert out.read_bytes() == want.stdout
 
 
 def _bench_line(p):
