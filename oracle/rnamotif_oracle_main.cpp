@@ -14,6 +14,8 @@
 #include <vector>
 #include "rm_cli.h"
 #include "rm_oracle.h"
+#include "rm_pack.h"
+#include <string>
 
 namespace {
 
@@ -68,6 +70,35 @@ int oracle_scan( void *self, const char *const *seqs, const int32_t *slens, int 
 	return 0;
 }
 
+// The packed entry points of the driver's pipeline (reader -> upload -> scan -> replay threads, and
+// the replay on several threads), so that the CPU tests run the host code the product runs: an
+// "upload" remembers which entries, the "scan" unpacks their text and calls the oracle.
+struct PackedBatch { const rma::PackFile *pk; int first, count; };
+
+int oracle_upload_packed( void *, const rma::PackFile *pk, int first, int count, void **handle, char *, size_t )
+{
+	*handle = new PackedBatch{ pk, first, count };
+	return 0;
+}
+
+int oracle_scan_uploaded( void *self, void *handle, const int32_t **hits, int64_t *n_hits, char *err, size_t errlen )
+{
+	PackedBatch	*b = ( PackedBatch * )handle;
+	std::vector<std::string>	text( size_t( b->count ) );
+	std::vector<const char *>	seqs( size_t( b->count ) );
+	std::vector<int32_t>	slens( size_t( b->count ) );
+	for( int i = 0; i < b->count; i++ ){
+		text[ i ] = b->pk->unpack( b->first + i );
+		seqs[ i ] = text[ i ].c_str();
+		slens[ i ] = int32_t( text[ i ].size() );
+	}
+	const int	n = b->count;
+	delete b;
+	return oracle_scan( self, seqs.data(), slens.data(), n, hits, n_hits, err, errlen );
+}
+
+void oracle_drop_uploaded( void *, void *handle ) { delete ( PackedBatch * )handle; }
+
 rma::ScanBackend make_oracle( const rma_program_t *prog, const rma_efndata_t *efn, const rma_efn2data_t *efn2 )
 {
 	rmo_set_efn2data( efn2 );	// tables for efn2() sites: the product's loader (checked against efn2_drv)
@@ -82,7 +113,9 @@ rma::ScanBackend make_oracle( const rma_program_t *prog, const rma_efndata_t *ef
 		ob->efn = &ob->own_efn;
 	}
 	rmo_hits_init( &ob->hits, prog );
-	return rma::ScanBackend{ ob, oracle_scan };
+	if( getenv( "RMO_NO_PIPELINE" ) )		// (the one-thread loop over text only)
+		return rma::ScanBackend{ ob, oracle_scan };
+	return rma::ScanBackend{ ob, oracle_scan, oracle_upload_packed, oracle_scan_uploaded, oracle_drop_uploaded };
 }
 
 }	// namespace

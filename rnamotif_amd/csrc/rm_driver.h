@@ -47,6 +47,12 @@ public:
 	// the text of an entry is rebuilt for the span of each hit only (PackFile::window), so a batch
 	// of a hundred million bases with a few thousand hits costs a few thousand small windows
 	void	replay_packed( const PackFile &pk, int first, const int32_t *hits, int64_t n, SearchStats &st );
+	// parallel replay (rm_driver.cpp): a worker's replayer writes to a buffer of its own and never
+	// prints the "#RM" header
+	void	set_out( FILE *out, bool header );
+	void	print_header( FILE *fp ) const { printer_.header( fp ); }
+	bool	header_pending() const { return printer_.header_pending(); }
+	void	header_done() { printer_.no_header(); }
 private:
 	void	one_hit( const int32_t *w, const char *sid, const char *sdef, int slen, const char *sbuf, SearchStats &st );
 	std::vector<char>	text_;		// strand buffer of the entry in hand, filled window by window

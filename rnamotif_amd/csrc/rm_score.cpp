@@ -690,7 +690,22 @@ bool ScoreVM::hit_independent( std::string *why ) const
 	entry.vt.resize( size_t( nv ) );
 	for( int i = 0; i < nv; i++ )
 		entry.vt[ i ] = vars[ i ]->type;		// (what BEGIN and the parms section left)
-	auto join_type = []( int a, int b ){ return a == b ? a : int( TY_TOP ); };
+	// (a variable that is undefined on one path and of type T on the other is "undefined or T", T + 50:
+	// an assignment of a T settles it either way -- the loop that assigns in its body)
+	auto join_type = []( int a, int b ){
+		if( a == b )
+			return a;
+		auto base = []( int x ){ return x >= 50 && x < 100 ? x - 50 : x; };
+		const bool	var_like = ( a == T_UNDEF || ( base( a ) >= T_INT && base( a ) <= T_STRING ) ) &&
+			( b == T_UNDEF || ( base( b ) >= T_INT && base( b ) <= T_STRING ) ) && a < 100 && b < 100;
+		if( !var_like )
+			return int( TY_TOP );
+		if( a == T_UNDEF )
+			return base( b ) + 50;
+		if( b == T_UNDEF )
+			return base( a ) + 50;
+		return base( a ) == base( b ) ? base( a ) + 50 : int( TY_TOP );
+	};
 	std::string	trouble;
 	auto merge = [&]( int pc, const State &s ){
 		if( pc < 0 || pc > int( pr.size() ) ){
@@ -717,14 +732,30 @@ bool ScoreVM::hit_independent( std::string *why ) const
 				changed = true;
 			}
 		}
-		if( t.stk.size() != s.stk.size() ){
-			trouble = "evaluation stacks of different depth meet";
-			return;
+		// After a || b (a && b) the VM leaves a below b on the path that evaluated b (do_ior score.c:2338
+		// jumps over b with a alone): the stacks that meet at the label differ in depth.  What follows
+		// reads the top -- an FJP, or an operator that would fail on the deeper path in any case -- so the
+		// shallower stack stands for both, its top joined with the deeper one's.
+		std::vector<int>	in = s.stk;
+		if( t.stk.size() != in.size() ){
+			if( t.stk.empty() || in.empty() ){
+				trouble = "an empty evaluation stack meets a value";
+				return;
+			}
+			const int	top_t = t.stk.back(), top_s = in.back();
+			if( in.size() > t.stk.size() )
+				in.resize( t.stk.size() );
+			else{
+				t.stk.resize( in.size() );
+				changed = true;
+			}
+			in.back() = top_s;
+			t.stk.back() = top_t;
 		}
 		for( size_t i = 0; i < t.stk.size(); i++ ){
-			const int	j = join_type( t.stk[ i ], s.stk[ i ] );
+			const int	j = join_type( t.stk[ i ], in[ i ] );
 			if( j != t.stk[ i ] ){
-				if( t.stk[ i ] == TY_MARK || s.stk[ i ] == TY_MARK ){
+				if( t.stk[ i ] == TY_MARK || in[ i ] == TY_MARK ){
 					trouble = "a mark meets a value";
 					return;
 				}
@@ -817,7 +848,8 @@ bool ScoreVM::hit_independent( std::string *why ) const
 			}else{
 				if( !( ( s.da >> v ) & 1 ) )
 					return no( "variable '" + vars[ size_t( v ) ]->name + "' may be read with an earlier hit's value" );
-				k.push_back( s.vt[ size_t( v ) ] == T_UNDEF ? int( TY_TOP ) : s.vt[ size_t( v ) ] );
+				const int	t = s.vt[ size_t( v ) ];
+				k.push_back( t == T_UNDEF ? int( TY_TOP ) : t >= 50 && t < 100 ? t - 50 : t );
 			}
 			break;
 		}
@@ -842,6 +874,10 @@ bool ScoreVM::hit_independent( std::string *why ) const
 			if( vt == T_UNDEF ){
 				// the first assignment ever latches the type: every assignment must agree on it
 				if( top != T_INT && top != T_FLOAT && top != T_STRING )
+					return no( "type of variable '" + vars[ size_t( v ) ]->name + "' depends on which hit assigns it first" );
+				vt = top;
+			}else if( vt >= 50 && vt < 100 ){
+				if( top != vt - 50 )
 					return no( "type of variable '" + vars[ size_t( v ) ]->name + "' depends on which hit assigns it first" );
 				vt = top;
 			}else if( vt == TY_TOP )
@@ -1824,6 +1860,32 @@ void ScoreVM::do_scl( const Inst &ip )	// :1138
 }
 
 // ---------------------------------------------------------------- print_match
+void HitPrinter::header( FILE *fp ) const
+{
+	fprintf( fp, "#RM scored\n" );
+	fprintf( fp, "#RM descr" );
+	auto name = [&]( const Strel *st ){
+		fprintf( fp, " %s", strel_name( st->type ) );
+		if( st->tag != nullptr ){
+			std::string	c;
+			for( const char *p = st->tag; *p; p++ ){
+				if( *p == '"' || *p == '\\' )
+					c += '\\';
+				c += *p;
+			}
+			fprintf( fp, "(tag='%s')", c.c_str() );
+		}
+	};
+	if( d_.lctx )
+		name( d_.lctx );
+	for( const Strel &st : d_.descr )
+		name( &st );
+	if( d_.rctx )
+		name( d_.rctx );
+	fprintf( fp, "\n" );
+	fprintf( fp, "#RM dfile %s\n", d_.args.have_dfname ? d_.args.dfname.c_str() : "(null)" );
+}
+
 void HitPrinter::print( const char *sid, const char *sdef, int comp, int slen, const char *sbuf, Ident *h_id )
 {
 	std::string	defline = std::string( ">" ) + sid + " " + sdef + "\n";
@@ -1870,28 +1932,7 @@ void HitPrinter::print( const char *sid, const char *sdef, int comp, int slen, c
 
 	if( first_ ){
 		first_ = false;
-		fprintf( out_, "#RM scored\n" );
-		fprintf( out_, "#RM descr" );
-		auto name = [&]( const Strel *st ){
-			fprintf( out_, " %s", strel_name( st->type ) );
-			if( st->tag != nullptr ){
-				std::string	c;
-				for( const char *p = st->tag; *p; p++ ){
-					if( *p == '"' || *p == '\\' )
-						c += '\\';
-					c += *p;
-				}
-				fprintf( out_, "(tag='%s')", c.c_str() );
-			}
-		};
-		if( d_.lctx )
-			name( d_.lctx );
-		for( const Strel &st : d_.descr )
-			name( &st );
-		if( d_.rctx )
-			name( d_.rctx );
-		fprintf( out_, "\n" );
-		fprintf( out_, "#RM dfile %s\n", d_.args.have_dfname ? d_.args.dfname.c_str() : "(null)" );
+		header( out_ );
 	}
 	if( h_id != nullptr ){
 		Hit	*hp = ( Hit * )h_id->val.pval;

@@ -134,6 +134,13 @@ public:
 	HitPrinter( Descriptor &d, FILE *out ) : d_( d ), out_( out ) {}
 	// the candidate's element state must already be in d.descr / lctx / rctx
 	void	print( const char *sid, const char *sdef, int comp, int slen, const char *sbuf, Ident *h_id );
+	// the three "#RM" lines that precede the first hit
+	void	header( FILE *fp ) const;
+	// several printers share one output (parallel replay): whoever puts the pieces together writes the
+	// header once, the printers never do
+	void	no_header() { first_ = false; }
+	bool	header_pending() const { return first_; }
+	void	set_out( FILE *fp ) { out_ = fp; }
 private:
 	Descriptor	&d_;
 	FILE	*out_;
