@@ -16,8 +16,8 @@ $B/rnamotif_pack /tmp/syn$N.rmpk /tmp/syn$N.fastn
 for i in 1 2; do
 for what in fastn rmpk; do
 	echo "== $N Mbase, $what, run $i"
-	( time RNAMOTIF_BATCH_BASES=64000000 RNAMOTIF_TIMING=1 $B/rnamotif -descr $D /tmp/syn$N.$what > /tmp/o_$what.txt ) 2> /tmp/err.txt
-	grep "real\|scanner created\|search done\|pack opened" /tmp/err.txt
+	( time RNAMOTIF_BATCH_BASES=${BB:-64000000} RNAMOTIF_TIMING=1 $B/rnamotif -descr $D /tmp/syn$N.$what > /tmp/o_$what.txt ) 2> /tmp/err.txt
+	grep "real\|scanner created\|search done\|pack opened\|replay on" /tmp/err.txt
 	python3 - <<PY
 import re
 t = open('/tmp/err.txt').read()

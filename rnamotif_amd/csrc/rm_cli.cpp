@@ -89,7 +89,10 @@ int cli_main( int argc, char **argv, BackendFactory make_backend )
 		ScanBackend	be = make_backend( pr.prog.get(), pr.efn.get(), pr.efn2.get() );
 		lap( "scanner created" );
 		const char	*bb = getenv( "RNAMOTIF_BATCH_BASES" );
-		int64_t	batch_bases = bb ? atoll( bb ) : ( int64_t( 1 ) << 28 );
+		// (64 Mbase per batch: sixteen batches to a gigabase, each two or three milliseconds in every
+		// stage of the pipeline -- reading, upload, kernels, replay -- so the stages overlap from the
+		// first tenth of the database on; 268 Mbase, the value until round 2, gave the pipeline four)
+		int64_t	batch_bases = bb ? atoll( bb ) : ( int64_t( 1 ) << 26 );
 		run_search( d, *pr.prog, be, stdout, batch_bases, nullptr );
 		lap( "search done" );
 		return 0;

@@ -481,6 +481,10 @@ private:
 			if( timing_ )
 				fprintf( stderr, "[timing] replay of %lld candidates: %.1f ms (done at +%.1f)\n", ( long long )b.n_hits,
 					std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(), lap_clock() );
+			if( b.own ){		// (a batch parsed from text: its words serve the next one)
+				recycle_words( std::move( b.own->codes ) );
+				recycle_words( std::move( b.own->amask ) );
+			}
 			b = Batch();		// (the batch's own pack goes before the count says it is done)
 			std::lock_guard<std::mutex>	lk( mu_ );
 			if( in_flight_ > 0 )
@@ -669,6 +673,7 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		if( !use_stdin && pl && seq_format_of( d.args.dbfmt ) == FMT_FASTN ){
 			// a FASTA file: read, packed and scanned in parallel as far as it is regular
 			FastaStream	fs;
+			fs.keep_mapping();		// (see there: unmapping stalls the batches still in flight)
 			if( fs.open( d.args.dbfnames[ f ], d.args.maxslen, parser_threads() ) ){
 				flush();
 				auto	t0 = std::chrono::steady_clock::now();

@@ -106,3 +106,4 @@ struct rmk_efn_args {
 	const rma_efn2data_t	*e2;	// efn2's tables, or null
 };
 hipError_t	rmk_launch_efn( int grid, hipStream_t s, const rmk_efn_args &a );
+hipError_t	rmk_preload_efn( void );

@@ -7,8 +7,30 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
+#include <new>
 
 namespace rma {
+
+void *pack_map_pages( size_t len )
+{
+	const size_t	huge = size_t( 2 ) << 20;
+	char	*m = static_cast<char *>( mmap( nullptr, len + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0 ) );
+	if( m == MAP_FAILED )
+		throw std::bad_alloc();
+	char	*a = reinterpret_cast<char *>( ( reinterpret_cast<uintptr_t>( m ) + huge - 1 ) & ~uintptr_t( huge - 1 ) );
+	if( a > m )
+		munmap( m, size_t( a - m ) );
+	if( a + len < m + len + huge )
+		munmap( a + len, size_t( ( m + len + huge ) - ( a + len ) ) );
+	( void )madvise( a, len, MADV_HUGEPAGE );
+	return a;
+}
+
+void pack_unmap_pages( void *p, size_t len )
+{
+	munmap( p, len );
+}
 
 static const char	PACK_MAGIC[ 9 ] = "RMAPACK1";
 

@@ -6,3 +6,11 @@ hipError_t rmk_launch_efn( int grid, hipStream_t s, const rmk_efn_args &a )
 		a.d_prog, a.db, a.hits, a.n_hits, a.t16, a.tlkey, a.loginc, a.e2 );
 	return hipGetLastError();
 }
+
+// the kernel's code object loaded now and not by its first launch (rma_scanner_warmup: 13 ms measured
+// in the first batch of a search, whose warm-up scan finds no candidate to give the kernel)
+hipError_t rmk_preload_efn( void )
+{
+	hipFuncAttributes	a;
+	return hipFuncGetAttributes( &a, reinterpret_cast<const void *>( &rma_efn_kernel<EFN_BLOCK> ) );
+}

@@ -242,6 +242,8 @@ __device__ inline unsigned long long rows_win( const unsigned long long *rows5, 
 	unsigned long long	W;
 	if( lim == 0 ){
 		// no mispair allowed: a plain AND of the shifted rows, done as soon as no end position is left
+		// (a copy of the loop per helix length, unrolled so that the LDS reads of all its steps are issued
+		// together, measured the same: trna.descr 3.26 / 1.94 ms against 3.25 / 1.92)
 		W = ~0ull;
 		for( int h = 0; h < hl0 && W; h++ ){
 			const int	qq = w0 - h - p_lo + 64;	// bit index into the padded vector

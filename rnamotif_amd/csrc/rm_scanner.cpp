@@ -1319,6 +1319,8 @@ extern "C" int rma_scanner_warmup( rma_scanner_t *sc, char *err, size_t errlen )
 		rc = rma_scan( sc, wdb, &wh, &wn, err, errlen );
 		rma_db_destroy( wdb );
 	}
+	if( sc->dprog.n_efn > 0 )
+		( void )rmk_preload_efn();
 	if( rc == 0 && sc->dsort.cap >= 4096 ){
 		// ... and one pass of the ordering over a cleared hit buffer
 		( void )hipMemsetAsync( sc->d_hits, 0, size_t( 4096 ) * sc->dprog.hit_stride * sizeof( int32_t ), sc->stream );

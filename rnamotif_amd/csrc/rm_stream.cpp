@@ -40,7 +40,7 @@ FastaStream::~FastaStream()
 	cv_room_.notify_all();
 	for( std::thread &t : pool_ )
 		t.join();
-	if( map_ != nullptr )
+	if( map_ != nullptr && !keep_map_ )
 		munmap( const_cast<char *>( map_ ), size_ );
 }
 
@@ -107,16 +107,69 @@ bool FastaStream::open( const std::string &path, int maxslen, int threads )
 		cur = gt[ g++ ];
 		starts_.push_back( cur );
 	}
-	const size_t	n = starts_.size();
 	starts_.push_back( size_ );
-	// workers take runs of entries so that a run is a few hundred KB of text
-	const size_t	avg = std::max<size_t>( 1, size_ / n );
-	const size_t	run = std::max<size_t>( 1, std::min<size_t>( 64, ( size_t( 256 ) << 10 ) / avg ) );
-	ring_ = std::max<size_t>( 4 * run * size_t( threads ), 64 );
-	run_ = run;
-	entries_.resize( ring_ );
-	for( int t = 0; t < threads; t++ )
-		pool_.emplace_back( [ this ](){ worker(); } );
+	threads_ = threads;
+	return true;
+}
+
+// Words of packed databases that have been handed out and freed again: the next batch takes them
+// instead of fresh memory, which would be touched for the first time -- a page fault per 4 KB --
+// while it is being filled (rm_pack.cpp's buffers are not zero-filled for the same reason).
+namespace {
+std::mutex	g_spare_mu;
+std::vector<PackWords>	g_spare;
+}
+
+void recycle_words( PackWords &&w )
+{
+	if( w.capacity() < ( size_t( 1 ) << 18 ) )
+		return;
+	std::lock_guard<std::mutex>	lk( g_spare_mu );
+	if( g_spare.size() < 12 )
+		g_spare.push_back( std::move( w ) );
+}
+
+static PackWords take_words( size_t n )
+{
+	PackWords	w;
+	{
+		std::lock_guard<std::mutex>	lk( g_spare_mu );
+		int	best = -1;
+		for( size_t i = 0; i < g_spare.size(); i++ )
+			if( g_spare[ i ].capacity() >= n && ( best < 0 || g_spare[ i ].capacity() < g_spare[ size_t( best ) ].capacity() ) )
+				best = int( i );
+		if( best >= 0 ){
+			w = std::move( g_spare[ size_t( best ) ] );
+			g_spare.erase( g_spare.begin() + best );
+		}
+	}
+	w.resize( n );		// (no fill: NoInitAlloc)
+	return w;
+}
+
+bool FastaStream::plan_to( size_t i )
+{
+	const size_t	n = starts_.size() - 1;
+	while( planned_ <= i ){
+		if( quit_ || planned_ >= n )
+			return false;
+		std::unique_ptr<Plan>	pl( new Plan );
+		pl->first = planned_;
+		int64_t	bytes = 0, mask_words = 0;
+		while( planned_ < n && ( pl->count == 0 || bytes < batch_bytes_ ) ){
+			const int64_t	extent = int64_t( starts_[ planned_ + 1 ] - starts_[ planned_ ] );
+			pl->base_off.push_back( mask_words * 32 );
+			mask_words += ( extent + 31 ) / 32;
+			bytes += extent;
+			pl->count++;
+			planned_++;
+		}
+		pl->meta.resize( pl->count );
+		pl->pk.reset( new PackFile );
+		pl->pk->codes = take_words( size_t( mask_words ) * 2 );
+		pl->pk->amask = take_words( size_t( mask_words ) );
+		plans_.push_back( std::move( pl ) );
+	}
 	return true;
 }
 
@@ -124,29 +177,35 @@ void FastaStream::worker()
 {
 	const size_t	n = starts_.size() - 1;
 	for( ; ; ){
-		const size_t	i0 = claim_.fetch_add( run_ );
-		if( i0 >= n )
+		const size_t	i = claim_.fetch_add( 1 );
+		if( i >= n )
 			return;
-		for( size_t i = i0; i < std::min( n, i0 + run_ ); i++ ){
-			{
-				std::unique_lock<std::mutex>	lk( mu_ );
-				cv_room_.wait( lk, [ & ]{ return quit_ || i < consumed_ + ring_; } );
-				if( quit_ )
-					return;
-			}
-			Entry	&e = entries_[ i % ring_ ];
-			parse( i, e );
-			{
-				std::lock_guard<std::mutex>	lk( mu_ );
-				e.done = true;
-			}
-			cv_done_.notify_all();
+		Plan	*pl = nullptr;
+		{
+			std::unique_lock<std::mutex>	lk( mu_ );
+			// not more than a few batches ahead of the reader of the batches
+			cv_room_.wait( lk, [ & ]{ return quit_ || i < planned_ || plans_.size() < 4; } );
+			if( quit_ || !plan_to( i ) )
+				return;
+			for( auto &p : plans_ )
+				if( i >= p->first && i < p->first + p->count )
+					pl = p.get();
+			if( pl == nullptr )
+				return;		// (its batch has been handed out truncated: the stream is over)
 		}
+		const size_t	k = i - pl->first;
+		parse( i, pl->meta[ k ], pl->pk->codes.data() + pl->base_off[ k ] / 16, pl->pk->amask.data() + pl->base_off[ k ] / 32 );
+		{
+			std::lock_guard<std::mutex>	lk( mu_ );
+			pl->done++;
+		}
+		cv_done_.notify_all();
 	}
 }
 
-// FN_fgetseq(), dbutil.c:42-128, on the bytes of entry i
-void FastaStream::parse( size_t i, Entry &e ) const
+// FN_fgetseq(), dbutil.c:42-128, on the bytes of entry i; the packed letters go to cw / mw, which
+// have room for as many letters as the entry has bytes
+void FastaStream::parse( size_t i, Meta &e, uint32_t *cw, uint32_t *mw ) const
 {
 	e.sid.clear();
 	e.sdef.clear();
@@ -184,34 +243,44 @@ void FastaStream::parse( size_t i, Entry &e ) const
 		e.sdef.assign( p, size_t( stop - p ) );
 		p = stop;
 	}
-	// the letters: one mask word and two code words per 32 bases
-	const size_t	bound = size_t( end - p );
-	e.codes.assign( ( bound + 31 ) / 32 * 2 + 2, 0 );
-	e.amask.assign( ( bound + 31 ) / 32 + 1, 0 );
-	uint32_t	*cw = e.codes.data(), *mw = e.amask.data();
+	// the letters: sixteen to a code word, thirty-two to a mask word, each word stored once
 	const unsigned char	*cls = CLASSES.cls;
 	size_t	n = 0;
+	uint32_t	cacc = 0, macc = 0;
 	for( const unsigned char *q = reinterpret_cast<const unsigned char *>( p ),
 		*qe = reinterpret_cast<const unsigned char *>( end ); q < qe; q++ ){
 		const unsigned	c = cls[ *q ];
 		if( c == 255 )
 			continue;
 		if( c < 4 )
-			cw[ n >> 4 ] |= c << ( 2 * ( n & 15 ) );
+			cacc |= c << ( 2 * ( n & 15 ) );
 		else{
-			mw[ n >> 5 ] |= 1u << ( n & 31 );
+			macc |= 1u << ( n & 31 );
 			e.exc.push_back( char( tolower( *q ) ) );
 		}
 		n++;
+		if( ( n & 15 ) == 0 ){
+			cw[ ( n >> 4 ) - 1 ] = cacc;
+			cacc = 0;
+			if( ( n & 31 ) == 0 ){
+				mw[ ( n >> 5 ) - 1 ] = macc;
+				macc = 0;
+			}
+		}
 	}
+	// the words the last letters leave unfinished, up to the entry's last 32-base boundary
+	size_t	written = n >> 4;
+	if( n & 15 )
+		cw[ written++ ] = cacc;
+	if( written & 1 )
+		cw[ written ] = 0;
+	if( n & 31 )
+		mw[ n >> 5 ] = macc;
 	if( n >= size_t( maxslen_ ) ){
 		e.anomaly = true;		// sequence to be truncated (or at the limit: left to the reader)
 		return;
 	}
 	e.slen = int32_t( n );
-	const size_t	nw1 = ( n + 31 ) / 32;
-	e.codes.resize( nw1 * 2 );
-	e.amask.resize( nw1 );
 }
 
 std::unique_ptr<PackFile> FastaStream::next( int64_t batch_bases )
@@ -219,35 +288,55 @@ std::unique_ptr<PackFile> FastaStream::next( int64_t batch_bases )
 	if( map_ == nullptr || stopped_at_ >= 0 )
 		return nullptr;
 	const size_t	n = starts_.size() - 1;
-	std::unique_ptr<PackFile>	pk( new PackFile );
-	while( consumed_ < n ){
-		Entry	&e = entries_[ consumed_ % ring_ ];
-		{
-			std::unique_lock<std::mutex>	lk( mu_ );
-			cv_done_.wait( lk, [ & ]{ return e.done; } );
-		}
-		if( e.anomaly ){
-			stopped_at_ = int64_t( starts_[ consumed_ ] );
-			{
-				std::lock_guard<std::mutex>	lk( mu_ );
-				quit_ = true;
-			}
-			cv_room_.notify_all();
-			break;
-		}
-		pk->append_packed( e.sid, e.sdef, e.codes, e.amask, e.exc, e.slen );
-		e.done = false;
+	if( !started_ ){
+		started_ = true;
+		batch_bytes_ = std::max<int64_t>( batch_bases, 1 );
+		for( int t = 0; t < threads_; t++ )
+			pool_.emplace_back( [ this ](){ worker(); } );
+	}
+	std::unique_ptr<Plan>	pl;
+	{
+		std::unique_lock<std::mutex>	lk( mu_ );
+		if( plans_.empty() && ( planned_ >= n || !plan_to( planned_ ) ) )
+			return nullptr;
+		Plan	*front = plans_.front().get();
+		cv_done_.wait( lk, [ & ]{ return front->done == front->count; } );
+		pl = std::move( plans_.front() );
+		plans_.pop_front();
+	}
+	cv_room_.notify_all();
+	// the entries in order, up to the first one the serial reader has something to say about
+	PackFile	&pk = *pl->pk;
+	size_t	good = 0;
+	while( good < pl->count && !pl->meta[ good ].anomaly )
+		good++;
+	if( good < pl->count ){
+		stopped_at_ = int64_t( starts_[ pl->first + good ] );
 		{
 			std::lock_guard<std::mutex>	lk( mu_ );
-			consumed_++;
+			quit_ = true;
 		}
 		cv_room_.notify_all();
-		if( pk->total_bases >= batch_bases )
-			break;
 	}
-	if( pk->count() == 0 )
+	if( good == 0 )
 		return nullptr;
-	return pk;
+	for( size_t k = 0; k < good; k++ ){
+		Meta	&m = pl->meta[ k ];
+		pk.base_off.push_back( pl->base_off[ k ] );
+		pk.exc_off.push_back( int64_t( pk.exc.size() ) );
+		pk.slen.push_back( m.slen );
+		pk.total_bases += m.slen;
+		pk.exc.insert( pk.exc.end(), m.exc.begin(), m.exc.end() );
+		pk.sid_off.push_back( int64_t( pk.text.size() ) );
+		pk.text.insert( pk.text.end(), m.sid.c_str(), m.sid.c_str() + strlen( m.sid.c_str() ) + 1 );
+		pk.sdef_off.push_back( int64_t( pk.text.size() ) );
+		pk.text.insert( pk.text.end(), m.sdef.c_str(), m.sdef.c_str() + strlen( m.sdef.c_str() ) + 1 );
+	}
+	// the arrays end with the last entry taken
+	const int64_t	end_words = pl->base_off[ good - 1 ] / 32 + ( int64_t( pl->meta[ good - 1 ].slen ) + 31 ) / 32;
+	pk.codes.resize( size_t( end_words ) * 2 );
+	pk.amask.resize( size_t( end_words ) );
+	return std::move( pl->pk );
 }
 
 }	// namespace rma

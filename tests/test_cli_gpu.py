@@ -174,6 +174,6 @@ def test_whole_program_throughput(built, workdir, tmp_path):
         res[what] = best + (hashlib.md5(out).hexdigest(), out.count(b"\n>"))
     print("\n200 Mbase:", {k: "search %.3f s = %.2f Gbases/s, whole program %.2f s" % (v[0], 0.2 / v[0], v[1]) for k, v in res.items()})
     assert len({v[2] for v in res.values()}) == 1 and res["text"][3] > 10000
-    assert 0.2 / res["text"][0] >= 1.5, res
-    assert 0.2 / res["pack"][0] >= 3.0, res          # (30-33 ms measured: read batch by batch while the batches before are searched)
+    # (no absolute floors here: wall-clock figures of a shared box belong to bench.py's cli_end_to_end leg
+    # and to profiles/; what must hold anywhere is that the pipeline beats the one-thread loop)
     assert res["text"][0] < res["text, one thread"][0]
