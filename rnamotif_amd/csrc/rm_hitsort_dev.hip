@@ -141,7 +141,11 @@ hipError_t DevHitSort::run( const int32_t *d_hits, int64_t n, int w_seq, int w_p
 	hipLaunchKernelGGL( hit_keys_kernel, dim3( unsigned( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, s,
 		d_hits, ( long long )n, stride, w, keys[ 0 ], vals[ 0 ], d_flag );
 	if( ( e = hipGetLastError() ) != hipSuccess ) return e;
-	const unsigned	bits = unsigned( w.seq + 1 + w.pos + w.rank + w.ord );
+	// All 64 bits of the key, whatever the fields in use: the library picks its kernels by the bit range,
+	// and a range that changes with the database means kernels that are loaded in the middle of a search
+	// (11 ms in the first batch, measured) instead of by the scanner's warm-up.  The extra passes over a
+	// few thousand keys cost microseconds.
+	const unsigned	bits = 64u;
 	size_t	bytes = 0;
 	if( ( e = rocprim::radix_sort_pairs( nullptr, bytes, keys[ 0 ], keys[ 1 ], vals[ 0 ], vals[ 1 ], size_t( n ), 0u, bits, s ) ) != hipSuccess ) return e;
 	if( bytes > tmp_bytes ){

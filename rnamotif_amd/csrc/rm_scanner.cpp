@@ -476,6 +476,9 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	sc->hit_cap = 1 << 17;
 	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
 	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_ctr ), 4 * sizeof( unsigned long long ), hipHostMallocDefault ) );
+	// page-locked room for the records of a usual batch (16 K of them) now, not in the first scan
+	sc->h_raw_cap = size_t( 16384 ) * sc->dprog.hit_stride;
+	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_raw ), sc->h_raw_cap * sizeof( int32_t ), hipHostMallocDefault ) );
 	if( sc->dsort.reserve( sc->hit_cap, sc->dprog.hit_stride ) != hipSuccess )
 		( void )hipGetLastError();	// (no room for the ordering's buffers: rma_scan_end orders on the host)
 	guard.p = nullptr;
@@ -1193,6 +1196,10 @@ static int scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, b
 		return 0;
 	if( launch_efn( sc, n, err, errlen ) )
 		return 1;
+	if( timing ){
+		HIPCHK( hipStreamSynchronize( sc->stream ) );
+		lap( "energies" );
+	}
 	const rma_db	*db = sc->fly.db;
 	const int	stride = sc->dprog.hit_stride;
 	// pinned staging buffer: the copy back is a single DMA
@@ -1214,6 +1221,10 @@ static int scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, b
 			sc->dsort.run( sc->d_hits, n, rma::bits_of( unsigned( db->n_seq > 0 ? db->n_seq - 1 : 0 ) ), rma::bits_of( unsigned( db->max_slen ) ),
 				rma::bits_of( unsigned( sc->dprog.w_winsize ) ), sc->stream ) == hipSuccess ){
 			int	flag = 1;
+			if( timing ){
+				HIPCHK( hipStreamSynchronize( sc->stream ) );
+				lap( "sorted" );
+			}
 			if( copy_back )
 				HIPCHK( hipMemcpyAsync( sc->h_raw, sc->dsort.d_out, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
 			HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->dsort.d_flag, sizeof( int ), hipMemcpyDeviceToHost, sc->stream ) );
@@ -1319,12 +1330,24 @@ extern "C" int rma_scanner_warmup( rma_scanner_t *sc, char *err, size_t errlen )
 		rc = rma_scan( sc, wdb, &wh, &wn, err, errlen );
 		rma_db_destroy( wdb );
 	}
-	if( sc->dprog.n_efn > 0 )
+	if( sc->dprog.n_efn > 0 ){
+		// ... and the energy kernel, which the scan above did not reach (no candidate): one launch over no
+		// records -- its code object, and the scratch memory its interval stack makes the runtime set
+		// aside at a kernel's first launch (9 ms in the first batch, measured)
 		( void )rmk_preload_efn();
+		rmk_efn_args	a{ sc->d_prog, DbView{}, sc->d_hits, 0ll, sc->have_efn ? sc->d_t16 : nullptr, sc->d_tlkey, sc->d_loginc, sc->d_efn2 };
+		( void )rmk_launch_efn( 1, sc->stream, a );
+		( void )hipStreamSynchronize( sc->stream );
+		( void )hipGetLastError();
+	}
 	if( rc == 0 && sc->dsort.cap >= 4096 ){
 		// ... and one pass of the ordering over a cleared hit buffer
 		( void )hipMemsetAsync( sc->d_hits, 0, size_t( 4096 ) * sc->dprog.hit_stride * sizeof( int32_t ), sc->stream );
 		( void )sc->dsort.run( sc->d_hits, 4096, 10, 20, 8, sc->stream );
+		// ... and the way back of the records, as a scan ends: the first copy of this size from the device
+		// sets up the engine that makes it
+		if( sc->h_raw_cap >= size_t( 4096 ) * sc->dprog.hit_stride )
+			( void )hipMemcpyAsync( sc->h_raw, sc->dsort.d_out, size_t( 4096 ) * sc->dprog.hit_stride * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream );
 		( void )hipStreamSynchronize( sc->stream );
 		( void )hipGetLastError();
 	}
