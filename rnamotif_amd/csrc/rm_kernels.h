@@ -60,7 +60,14 @@ struct HitBuf {
 #endif
 #define SHORT_ENTRY_MEAN	4000	// ... which are those whose entries average less than this
 #define SPILL_ITEMS		8192	// queue items per workgroup that may overflow into HBM (32 KB each, 64 MB in all)
-#define SEARCH_BLOCK		256	// lanes of a search workgroup
+#define SEARCH_BLOCK		256	// lanes of a search workgroup of the lean instances
+// ... and of the general instances: ONE wave.  The waves of a four-wave workgroup met at the end of
+// every tile, and the tile's second round -- a few dozen continuations, each a long walk -- kept one of
+// them busy while three waited: 23 % (pk1), 44 % (qu+tr) and 32 % (pk_j1+2) of all wave cycles,
+// RNAMOTIF_DBG=34.  A wave that is its own workgroup waits for nobody; tiles are a quarter the size.
+#ifndef GENERAL_BLOCK
+#define GENERAL_BLOCK		64
+#endif
 #define EFN_BLOCK		256	// lanes of an efn workgroup
 
 // ---------------------------------------------------------------- kernel instances

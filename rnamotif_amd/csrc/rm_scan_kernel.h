@@ -1256,11 +1256,12 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 #define RMK_DEFINE_LAUNCHER( name_, LEAN_, G_, KINDS_, POOL_ ) \
 hipError_t name_( int grid, size_t lds, hipStream_t s, const rmk_search_args &a ) \
 { \
-	auto	kernel = &rma_search_kernel<SEARCH_BLOCK, LEAN_, G_, KINDS_, POOL_>; \
+	constexpr int	BLOCK_ = ( LEAN_ ) ? SEARCH_BLOCK : GENERAL_BLOCK; \
+	auto	kernel = &rma_search_kernel<BLOCK_, LEAN_, G_, KINDS_, POOL_>; \
 	hipError_t	e = hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ); \
 	if( e != hipSuccess ) \
 		return e; \
-	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( SEARCH_BLOCK ), lds, s, \
+	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( BLOCK_ ), lds, s, \
 		a.d_prog, a.prog_bytes, a.qcap, a.db, a.hb, a.tile_bytes, a.dbg ); \
 	return hipGetLastError(); \
 }

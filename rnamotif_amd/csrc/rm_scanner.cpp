@@ -210,7 +210,8 @@ struct rma_scanner {
 	rma::DevHitSort	dsort;		// ordering on the device (rm_hitsort_dev.h)
 	unsigned long long	*h_ctr = nullptr;	// pinned: the counters a launch leaves
 	int	tile_t = 2048;
-	int	grid_blocks = 0;
+	int	grid_blocks = 0;		// most workgroups of a launch of a lean instance (eight of four waves per CU)
+	int	spill_blocks = 0;		// workgroups d_spill has areas for
 	int	kinds = 0;			// RMD_KIND_* of the descriptor
 	// the scan between rma_scan_begin() and rma_scan_end()
 	struct InFlight {
@@ -313,9 +314,9 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
-	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * SEARCH_BLOCK * 4;
+	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;
 	if( !lean && dp.split_s >= 0 )		// resume states of the levels up to the split level, queue of continuations
-		lds += size_t( dp.split_s + 1 ) * SEARCH_BLOCK * 8 + size_t( DEEP_QUEUE ) * ( 2 + 2 * ( dp.split_s + 1 ) ) * 4;
+		lds += size_t( dp.split_s + 1 ) * GENERAL_BLOCK * 8 + size_t( DEEP_QUEUE ) * ( 2 + 2 * ( dp.split_s + 1 ) ) * 4;
 	return lds;
 }
 
@@ -389,8 +390,11 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	hipDeviceProp_t	prop;
 	HIPCHK( hipGetDeviceProperties( &prop, device ) );
 	sc->grid_blocks = prop.multiProcessorCount * 8;
-	sc->spill_cap = sc->opt.spill >= 0 ? sc->opt.spill : SPILL_ITEMS;	// (tests: 0 = overflow searched in place)
-	HIPCHK( hipMalloc( &sc->d_spill, std::max<size_t>( size_t( sc->grid_blocks ) * sc->spill_cap, 1 ) * sizeof( unsigned ) ) );
+	// (the general instances run workgroups of one wave, four times as many, on tiles a quarter the size)
+	const int	per_wave0 = sc->dprog.lean_ok ? 1 : SEARCH_BLOCK / GENERAL_BLOCK;
+	sc->spill_blocks = sc->grid_blocks * per_wave0;
+	sc->spill_cap = sc->opt.spill >= 0 ? sc->opt.spill : SPILL_ITEMS / per_wave0;	// (tests: 0 = overflow searched in place)
+	HIPCHK( hipMalloc( &sc->d_spill, std::max<size_t>( size_t( sc->spill_blocks ) * sc->spill_cap, 1 ) * sizeof( unsigned ) ) );
 	if( sc->dprog.lean_ok ){
 		// The search of a tile ends with a few long-running items on a few lanes, so fewer,
 		// larger tiles are better as long as four workgroups still share a CU's 160 KB of LDS
@@ -450,15 +454,17 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 			sc->qcap += 256;
 	}
 	if( !sc->dprog.lean_ok ){
-		// general instance: its records take 12 bytes per level and lane of LDS next to the tile;
-		// as many workgroups per CU as still leave a tile of a few thousand positions (what the
-		// queue cannot hold spills to HBM)
-		sc->qcap = 512;
+		// general instance: workgroups of one wave (GENERAL_BLOCK), as many per SIMD as the registers allow
+		// (GENERAL_WAVES) and as still leave every one of them a tile of a thousand positions or more next
+		// to its records -- 12 bytes per level and lane -- and its queue (what the queue cannot hold spills
+		// to HBM)
+		const int	per_wave = SEARCH_BLOCK / GENERAL_BLOCK;	// workgroups where one of four waves stood
+		sc->qcap = 512 / per_wave < 128 ? 128 : 512 / per_wave;
 		sc->tile_t = 1024;
 		bool	found = false;
 		for( int wg = GENERAL_WAVES( sc->kinds & RMD_KIND_TQ ); wg >= 1 && !found; wg-- ){
-			const size_t	budget = ( 160 * 1024 ) / wg - 2560;	// (static __shared__ -- 1 KB of it the pre-filter's wave buffers -- and allocation granules)
-			for( int t = 8192; t >= ( wg > 1 ? 3072 : 1024 ); t -= 256 )
+			const size_t	budget = ( 160 * 1024 ) / ( wg * per_wave ) - ( per_wave > 1 ? 1024 : 2560 );	// (static __shared__ -- the pre-filter's wave buffers -- and allocation granules)
+			for( int t = 8192 / per_wave; t >= ( wg > 1 ? 3072 / per_wave : 1024 / per_wave ); t -= 256 )
 				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, false, sc->qcap ) <= budget ){
 					sc->tile_t = t;
 					found = true;
@@ -1049,7 +1055,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	f.inst = pooled ? RMK_LEAN_POOL : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
 		sc->kinds == 0 ? RMK_GEN_PLAIN : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ : RMK_GEN_PKTQ;
 	const int64_t	n_units = f.grouped ? ( lay->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : lay->n_tiles;
-	f.grid = int( std::min<int64_t>( n_units, sc->grid_blocks ) );
+	f.grid = int( std::min<int64_t>( n_units, f.lean ? sc->grid_blocks : sc->spill_blocks ) );
 	// the database's upload and the tiling's, on the device's upload stream, come first
 	HIPCHK( hipStreamWaitEvent( sc->stream, db->ready, 0 ) );
 	HIPCHK( hipStreamWaitEvent( sc->stream, lay->ready, 0 ) );
@@ -1086,7 +1092,7 @@ static int search_finish( rma_scanner_t *sc, int64_t *n_hits, float *search_ms, 
 				( void )hipFree( sc->d_spill );
 				sc->d_spill = nullptr;
 				sc->spill_cap = int( need ) + 1024;
-				HIPCHK( hipMalloc( &sc->d_spill, size_t( sc->grid_blocks ) * sc->spill_cap * sizeof( unsigned ) ) );
+				HIPCHK( hipMalloc( &sc->d_spill, size_t( sc->spill_blocks ) * sc->spill_cap * sizeof( unsigned ) ) );
 				again = true;
 			}
 		}
