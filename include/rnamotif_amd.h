@@ -130,6 +130,19 @@ int	rma_pack_pin( rma_pack_t *pk, char *err, size_t errlen );
  * reference prints.  Files that are packed databases already are appended as they are. */
 int	rma_pack_read( const char *const *paths, int32_t n_paths, const char *fmt, int32_t maxslen, int32_t threads,
 		rma_pack_t **out, char *err, size_t errlen );
+/* A rank's share of a database without reading the rest (one process per GPU).
+ * rma_database_index(): the entries of the files in order and an upper bound of each one's length --
+ * its bytes in a FASTA file ('>' found by all threads, nothing parsed), its length in a packed
+ * database -- for the ranks to divide among themselves; *extent is to be released with rma_free().
+ * rma_pack_read_entries(): the entries with the given numbers (ascending), read and packed; the
+ * other entries' bytes are not touched.  Both return 2, with nothing made, when the files can only be
+ * read whole -- -fmt pir | gb, a file that cannot be mapped, an entry the serial reader has a
+ * diagnostic for: the caller then reads everything with rma_pack_read(). */
+int	rma_database_index( const char *const *paths, int32_t n_paths, const char *fmt, int32_t threads,
+		int64_t **extent, int32_t *n_entries, char *err, size_t errlen );
+int	rma_pack_read_entries( const char *const *paths, int32_t n_paths, const char *fmt, int32_t maxslen, int32_t threads,
+		const int32_t *entry, int32_t n, rma_pack_t **out, char *err, size_t errlen );
+void	rma_free( void *p );
 /* Any n entries of a packed database, entry[i] with start positions pos_lo[i] <= szero < pos_hi[i]
  * (NULL: all), straight into HBM: what one rank of a multi-GPU search takes of a database every
  * rank has read.  Hit records number the entries 0 .. n-1 in the order given. */

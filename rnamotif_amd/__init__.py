@@ -84,6 +84,9 @@ def lib() -> C.CDLL:
     L.rma_db_create_packed.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_pack_write.argtypes = [C.c_char_p, cpp, cpp, cpp, i32p, C.c_int32, C.c_char_p, C.c_size_t]
     L.rma_pack_read.argtypes = [cpp, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_database_index.argtypes = [cpp, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(i64p), i32p, C.c_char_p, C.c_size_t]
+    L.rma_pack_read_entries.argtypes = [cpp, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_free.argtypes = [vp]
     L.rma_db_create_packed_ranges.argtypes = [vp, vp, i32p, i32p, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_replay_pack.argtypes = [vp, vp, C.c_int32, i32p, C.c_int64, i64p, C.c_char_p, C.c_size_t]
     L.rma_sort_hits.argtypes = [i32p, C.c_int64, C.c_int32, i32p, C.c_char_p, C.c_size_t]
@@ -476,6 +479,21 @@ class Pack:
         _check(L.rma_pack_read(arr, len(paths), fmt.encode() if fmt else None, maxslen, threads, C.byref(h), err, _ERRLEN), err)
         return Pack(_handle=h)
 
+    @staticmethod
+    def read_entries(paths: Sequence[str], entries: Sequence[int], fmt: str = "", maxslen: int = 0, threads: int = 0) -> Optional["Pack"]:
+        """Only the entries with these numbers (ascending; numbered over all files as database_index()
+        counts them), read and packed (rma_pack_read_entries); None when the files can only be read whole."""
+        L = lib()
+        h = C.c_void_p()
+        err = C.create_string_buffer(_ERRLEN)
+        arr = _cstr_array([p.encode() for p in paths])
+        ent = (C.c_int32 * max(len(entries), 1))(*[int(e) for e in entries])
+        rc = L.rma_pack_read_entries(arr, len(paths), fmt.encode() if fmt else None, maxslen, threads, ent, len(entries), C.byref(h), err, _ERRLEN)
+        if rc == 2:
+            return None
+        _check(rc, err)
+        return Pack(_handle=h)
+
     def pin(self) -> None:
         """Page-lock the packed words: uploads from this pack are DMA, asynchronous (rma_pack_pin)."""
         err = C.create_string_buffer(_ERRLEN)
@@ -516,6 +534,23 @@ class Pack:
             self.close()
         except Exception:
             pass
+
+
+def database_index(paths: Sequence[str], fmt: str = "", threads: int = 0) -> Optional[List[int]]:
+    """The entries of the sequence files, in order, each with an upper bound of its length -- without
+    reading the database (rma_database_index); None when the files can only be read whole."""
+    L = lib()
+    ext = C.POINTER(C.c_int64)()
+    n = C.c_int32()
+    err = C.create_string_buffer(_ERRLEN)
+    arr = _cstr_array([p.encode() for p in paths])
+    rc = L.rma_database_index(arr, len(paths), fmt.encode() if fmt else None, threads, C.byref(ext), C.byref(n), err, _ERRLEN)
+    if rc == 2:
+        return None
+    _check(rc, err)
+    out = [int(ext[i]) for i in range(n.value)]
+    L.rma_free(ext)
+    return out
 
 
 def synthetic_records(k: int, length: int = 1_000_000, seed: int = 20240601) -> List[bytes]:

@@ -10,6 +10,8 @@
 #include <cctype>
 #include <cstddef>
 #include <cstring>
+#include <cstdlib>
+#include <memory>
 
 struct rma_descr {
 	rma::Prepared	pr;
@@ -283,6 +285,115 @@ extern "C" int rma_pack_read( const char *const *paths, int32_t n_paths, const c
 		return set_err( err, errlen, x.what() );
 	}
 	*out = pk;
+	return 0;
+}
+
+// ---------------------------------------------------------------- a rank's share of a database
+// What every rank of a multi-GPU search can know of the database without reading it: its entries and
+// an upper bound of each one's length -- from the tables of a packed database, or from the '>' of a
+// FASTA file (found by all threads at once; nothing is parsed).
+extern "C" int rma_database_index( const char *const *paths, int32_t n_paths, const char *fmt, int32_t threads,
+	int64_t **extent, int32_t *n_entries, char *err, size_t errlen )
+{
+	*extent = nullptr;
+	*n_entries = 0;
+	try{
+		if( rma::seq_format_of( fmt ? fmt : "" ) != rma::FMT_FASTN )
+			return 2;		// (pir, gb: through the serial readers only)
+		std::vector<int64_t>	ext;
+		for( int f = 0; f < n_paths; f++ ){
+			const std::string	path = paths[ f ];
+			if( rma::PackFile::is_pack( path ) ){
+				rma::PackFile	pf;
+				std::string	e;
+				if( !pf.open( path, e ) )
+					return set_err( err, errlen, e.c_str() );
+				for( int i = 0; i < pf.count(); i++ )
+					ext.push_back( pf.slen[ i ] );
+				continue;
+			}
+			rma::FastaStream	fs;
+			if( !fs.open( path, 30000001, threads > 0 ? threads : 8 ) )
+				return 2;
+			for( size_t i = 0; i < fs.n_entries(); i++ )
+				ext.push_back( fs.extent( i ) );
+		}
+		if( ext.size() > size_t( 0x7fffffff ) )
+			return 2;
+		int64_t	*out = static_cast<int64_t *>( malloc( std::max<size_t>( ext.size(), 1 ) * sizeof( int64_t ) ) );
+		if( out == nullptr )
+			return set_err( err, errlen, "out of memory" );
+		memcpy( out, ext.data(), ext.size() * sizeof( int64_t ) );
+		*extent = out;
+		*n_entries = int32_t( ext.size() );
+		return 0;
+	}catch( std::exception &x ){
+		return set_err( err, errlen, x.what() );
+	}
+}
+
+extern "C" void rma_free( void *p ) { free( p ); }
+
+// Entries entry[ 0 .. n ) (numbers in the whole database as rma_database_index() counts them,
+// ascending) read, packed, and nothing else.  2: one of them needs the serial reader's diagnostics.
+extern "C" int rma_pack_read_entries( const char *const *paths, int32_t n_paths, const char *fmt, int32_t maxslen, int32_t threads,
+	const int32_t *entry, int32_t n, rma_pack_t **out, char *err, size_t errlen )
+{
+	*out = nullptr;
+	if( rma::seq_format_of( fmt ? fmt : "" ) != rma::FMT_FASTN )
+		return 2;
+	for( int i = 1; i < n; i++ )
+		if( entry[ i ] <= entry[ i - 1 ] )
+			return set_err( err, errlen, "rma_pack_read_entries: entry numbers must ascend" );
+	std::unique_ptr<rma_pack>	pk( new rma_pack );
+	const int	lim = maxslen > 0 ? maxslen + 1 : 30000000 + 1;
+	try{
+		int64_t	first_of_file = 0;
+		int	at = 0;		// next of entry[] to serve
+		for( int f = 0; f < n_paths && at < n; f++ ){
+			const std::string	path = paths[ f ];
+			if( rma::PackFile::is_pack( path ) ){
+				rma::PackFile	one;
+				std::string	e;
+				if( !one.open( path, e ) )
+					return set_err( err, errlen, e.c_str() );
+				while( at < n && entry[ at ] < first_of_file + one.count() ){
+					// a run of consecutive entries: one read
+					const int	i0 = int( entry[ at ] - first_of_file );
+					int	cnt = 1;
+					while( at + cnt < n && entry[ at + cnt ] == entry[ at ] + cnt && i0 + cnt < one.count() )
+						cnt++;
+					if( !one.ensure_range( i0, cnt, e ) )
+						return set_err( err, errlen, e.c_str() );
+					for( int i = i0; i < i0 + cnt; i++ ){
+						const int64_t	w1 = one.base_off[ i ] / 32, nw1 = ( int64_t( one.slen[ i ] ) + 31 ) / 32;
+						const int64_t	x0 = one.exc_off[ i ], x1 = i + 1 < one.count() ? one.exc_off[ i + 1 ] : int64_t( one.exc.size() );
+						pk->pf.append_packed( one.sid( i ), one.sdef( i ),
+							std::vector<uint32_t>( one.codes.begin() + 2 * w1, one.codes.begin() + 2 * ( w1 + nw1 ) ),
+							std::vector<uint32_t>( one.amask.begin() + w1, one.amask.begin() + w1 + nw1 ),
+							std::vector<char>( one.exc.begin() + x0, one.exc.begin() + x1 ), one.slen[ i ] );
+					}
+					at += cnt;
+				}
+				first_of_file += one.count();
+				continue;
+			}
+			rma::FastaStream	fs;
+			if( !fs.open( path, lim, threads > 0 ? threads : 8 ) )
+				return 2;
+			std::vector<int32_t>	local;
+			while( at < n && entry[ at ] < first_of_file + int64_t( fs.n_entries() ) )
+				local.push_back( int32_t( entry[ at++ ] - first_of_file ) );
+			if( !fs.read_entries( local.data(), local.size(), pk->pf ) )
+				return 2;
+			first_of_file += int64_t( fs.n_entries() );
+		}
+		if( at < n )
+			return set_err( err, errlen, "rma_pack_read_entries: entry number beyond the database" );
+	}catch( std::exception &x ){
+		return set_err( err, errlen, x.what() );
+	}
+	*out = pk.release();
 	return 0;
 }
 

@@ -326,6 +326,24 @@ bool PackFile::ensure( int n, std::string &err )
 	return true;
 }
 
+bool PackFile::ensure_range( int first, int count, std::string &err )
+{
+	if( !src_ || count <= 0 )
+		return true;
+	if( first < 0 || first + count > this->count() ){
+		err = "entries outside the packed database '" + src_->path + "'.";
+		return false;
+	}
+	const int	last = first + count - 1;
+	const int64_t	b0 = base_off[ first ], b1 = base_off[ last ] + ( ( int64_t( slen[ last ] ) + 31 ) / 32 ) * 32;
+	const size_t	c0 = size_t( b0 / 16 ), c1 = size_t( b1 / 16 ), m0 = size_t( b0 / 32 ), m1 = size_t( b1 / 32 );
+	bool	ok = c1 <= c0 || pread_parallel( src_->fd, codes.data() + c0, ( c1 - c0 ) * 4, src_->codes_at + int64_t( c0 ) * 4 );
+	ok = ok && ( m1 <= m0 || pread_parallel( src_->fd, amask.data() + m0, ( m1 - m0 ) * 4, src_->amask_at + int64_t( m0 ) * 4 ) );
+	if( !ok )
+		err = "read error on packed database '" + src_->path + "'.";
+	return ok;
+}
+
 bool PackFile::load( const std::string &path, std::string &err )
 {
 	return open( path, err ) && ensure( count(), err );

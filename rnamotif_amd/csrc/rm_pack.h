@@ -104,6 +104,9 @@ struct PackFile {
 	// size after open(): readers of earlier entries are not disturbed by ensure().
 	bool	open( const std::string &path, std::string &err );
 	bool	ensure( int n, std::string &err );
+	// after open(): the packed bases of entries first .. first+count-1 only (a rank of a multi-GPU
+	// search reads its share; pages of the arrays that belong to other entries are never touched)
+	bool	ensure_range( int first, int count, std::string &err );
 	static bool	is_pack( const std::string &path );
 private:
 	void	index_text();

@@ -283,6 +283,55 @@ void FastaStream::parse( size_t i, Meta &e, uint32_t *cw, uint32_t *mw ) const
 	e.slen = int32_t( n );
 }
 
+bool FastaStream::read_entries( const int32_t *which, size_t n, PackFile &pk )
+{
+	if( n == 0 )
+		return true;
+	if( map_ == nullptr )
+		return false;
+	std::vector<int64_t>	base_off( n );
+	int64_t	mask_words = 0;
+	for( size_t k = 0; k < n; k++ ){
+		if( which[ k ] < 0 || size_t( which[ k ] ) >= n_entries() )
+			return false;
+		base_off[ k ] = mask_words * 32;
+		mask_words += ( extent( size_t( which[ k ] ) ) + 31 ) / 32;
+	}
+	const size_t	c0 = pk.codes.size(), m0 = pk.amask.size();
+	pk.codes.resize( c0 + size_t( mask_words ) * 2 );
+	pk.amask.resize( m0 + size_t( mask_words ) );
+	std::vector<Meta>	meta( n );
+	std::atomic<size_t>	next_k{ 0 };
+	std::vector<std::thread>	ts;
+	const int	nt = int( std::min<size_t>( size_t( std::max( threads_, 1 ) ), n ) );
+	for( int t = 0; t < nt; t++ )
+		ts.emplace_back( [ & ](){
+			for( size_t k; ( k = next_k.fetch_add( 1 ) ) < n; )
+				parse( size_t( which[ k ] ), meta[ k ], pk.codes.data() + c0 + base_off[ k ] / 16, pk.amask.data() + m0 + base_off[ k ] / 32 );
+		} );
+	for( std::thread &t : ts )
+		t.join();
+	for( size_t k = 0; k < n; k++ )
+		if( meta[ k ].anomaly ){
+			pk.codes.resize( c0 );
+			pk.amask.resize( m0 );
+			return false;
+		}
+	for( size_t k = 0; k < n; k++ ){
+		Meta	&m = meta[ k ];
+		pk.base_off.push_back( int64_t( m0 ) * 32 + base_off[ k ] );
+		pk.exc_off.push_back( int64_t( pk.exc.size() ) );
+		pk.slen.push_back( m.slen );
+		pk.total_bases += m.slen;
+		pk.exc.insert( pk.exc.end(), m.exc.begin(), m.exc.end() );
+		pk.sid_off.push_back( int64_t( pk.text.size() ) );
+		pk.text.insert( pk.text.end(), m.sid.c_str(), m.sid.c_str() + strlen( m.sid.c_str() ) + 1 );
+		pk.sdef_off.push_back( int64_t( pk.text.size() ) );
+		pk.text.insert( pk.text.end(), m.sdef.c_str(), m.sdef.c_str() + strlen( m.sdef.c_str() ) + 1 );
+	}
+	return true;
+}
+
 std::unique_ptr<PackFile> FastaStream::next( int64_t batch_bases )
 {
 	if( map_ == nullptr || stopped_at_ >= 0 )

@@ -40,6 +40,15 @@ public:
 	// from, or -1 when the file is finished.  (The batch size of the first call holds for the file.)
 	std::unique_ptr<PackFile>	next( int64_t batch_bases );
 	int64_t	stopped_at() const { return stopped_at_; }
+	// The entries of the file as open() found them (before anything is parsed): how many, and how many
+	// bytes of the file each one takes -- an upper bound of its letters.  What the ranks of a multi-GPU
+	// search divide among themselves without reading the database (rma_database_index).
+	size_t	n_entries() const { return starts_.empty() ? 0 : starts_.size() - 1; }
+	int64_t	extent( size_t i ) const { return int64_t( starts_[ i + 1 ] - starts_[ i ] ); }
+	// Entries which[ 0 .. n ) (ascending) parsed and packed into pk, nothing else of the file touched.
+	// false: one of them is an entry the serial reader has something to say about (nothing is returned).
+	// Not to be mixed with next() on the same stream.
+	bool	read_entries( const int32_t *which, size_t n, PackFile &pk );
 	// Leave the file mapped when the stream goes away.  Unmapping a gigabyte takes the address space's
 	// lock for tens of milliseconds, during which no other thread of the process gets a page fault
 	// served -- the uploads and scans of the last batches wait (measured: 20-30 ms each instead of 2.5).

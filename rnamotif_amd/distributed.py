@@ -60,6 +60,31 @@ def partition_ranges(lengths: Sequence[int], world: int, max_chunk: int = 0) -> 
     return parts
 
 
+def partition_slices(extents: Sequence[int], world: int, max_chunk: int = 0) -> List[List[Tuple[int, int, int]]]:
+    """partition_ranges() for entries whose lengths are known as upper bounds only (their bytes in
+    the file: what the ranks know before anybody has read the database): per rank a list of
+    (entry, j, k) -- slice j of k of the entry's start positions, k = 1 for a whole entry -- sorted by
+    entry.  A rank that holds a slice reads the whole entry and turns (j, k) into the positions
+    [len * j // k, len * (j + 1) // k) once it knows the length; every rank does that alike."""
+    total = sum(extents)
+    if max_chunk <= 0:
+        max_chunk = max(1, -(-total // max(world, 1)))
+    work: List[Tuple[int, int, int, int]] = []          # (weight, entry, j, k)
+    for i, n in enumerate(extents):
+        k = 1 if n <= max_chunk else -(-n // max_chunk)
+        for j in range(k):
+            work.append((n // k, i, j, k))
+    loads = [0] * world
+    parts: List[List[Tuple[int, int, int]]] = [[] for _ in range(world)]
+    for w in sorted(work, key=lambda w: (-w[0], w[1], w[2])):
+        r = min(range(world), key=lambda r: (loads[r], r))
+        parts[r].append((w[1], w[2], w[3]))
+        loads[r] += w[0]
+    for p in parts:
+        p.sort()
+    return parts
+
+
 def all_ok(ok: bool, device=None) -> bool:
     """True on every rank iff every rank passes True: one MIN all-reduce.  A rank that fails
     before the gather (no scanner, no memory, a bad file) says so here instead of leaving the

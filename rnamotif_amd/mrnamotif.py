@@ -27,7 +27,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 import rnamotif_amd as R
-from rnamotif_amd.distributed import all_ok, gather_hits, partition_ranges, sort_hits
+from rnamotif_amd.distributed import all_ok, gather_hits, partition_ranges, partition_slices, sort_hits
 
 _VALUE_OPTS = {"-descr", "-xdescr", "-xdfname", "-N", "-fmt"}
 
@@ -60,6 +60,41 @@ def _read_database(argv: Sequence[str], files: Sequence[str]) -> "R.Pack":
 
 def _device_index(local_rank: int) -> int:
     return int(os.environ.get("RNAMOTIF_DEVICE", local_rank))
+
+
+def _read_share(argv: Sequence[str], files: Sequence[str], world: int, rank: int, dev):
+    """What this rank reads and what it scans of it: (pack, [(entry, lo, hi)] with entry numbers of the
+    whole database, the entries' numbers within pack).  With several ranks every rank but the first
+    reads only its own entries (rma_database_index + rma_pack_read_entries: a gigabase parsed once per
+    node, not once per rank); rank 0 reads them all, for it prints the hits of all.  Files that can only
+    be read whole (pir, gb, entries with reader diagnostics, -N truncation) are read whole by everyone,
+    as one rank alone does."""
+    fmt, n = _option(argv, "-fmt"), _option(argv, "-N")
+    pack = None
+    if world > 1:
+        ext = R.database_index(list(files), fmt=fmt)
+        if all_ok(ext is not None, dev):
+            parts = partition_slices(ext, world)[rank]
+            ents = sorted(set(e for e, _, _ in parts))
+            if rank == 0:
+                pack = _read_database(argv, files)
+                ok = pack.count == len(ext)
+                local = {e: e for e in ents}
+            else:
+                pack = R.Pack.read_entries(list(files), ents, fmt=fmt, maxslen=int(n) if n else 0)
+                ok = pack is not None
+                local = {e: i for i, e in enumerate(ents)}
+            if all_ok(ok, dev):
+                mine = []
+                for e, j, k in parts:
+                    slen = R.lib().rma_pack_slen(pack._h, local[e])
+                    mine.append((e, slen * j // k, slen * (j + 1) // k) if k > 1 else (e, 0, slen))
+                return pack, mine, [local[e] for e, _, _ in parts]
+            if rank != 0:
+                pack = None
+    pack = _read_database(argv, files) if world == 1 or rank != 0 or pack is None else pack
+    mine = partition_ranges(pack.lengths(), world)[rank]
+    return pack, mine, [i for i, _, _ in mine]
 
 
 def _scan_shard(descr, pack, entries, ranges, local_rank: int, on_device: bool = False):
@@ -128,15 +163,14 @@ def run(argv: Sequence[str], out_path: str = "-") -> int:
         files = database_files(argv)
         if not files:
             raise R.RnamotifError("mrnamotif: no sequence file")
-        pack = _read_database(argv, files)
         if rank == 0 and "-descr" in argv:
             mx = "UNBND" if descr.maxlen == 0x7fffffff else str(descr.maxlen)
             sys.stderr.write(f"{_option(argv, '-descr')}: complete descr length: min/max = {descr.minlen}/{mx}\n")
-        mine = partition_ranges(pack.lengths(), world)[rank]
+        pack, mine, local = _read_share(argv, files, world, rank, dev)
         if native is not None:
-            held = _scan_shard(descr, pack, [i for i, _, _ in mine], [(lo, hi) for _, lo, hi in mine], local_rank, on_device=True)
+            held = _scan_shard(descr, pack, local, [(lo, hi) for _, lo, hi in mine], local_rank, on_device=True)
         else:
-            hits = _scan_shard(descr, pack, [i for i, _, _ in mine], [(lo, hi) for _, lo, hi in mine], local_rank)
+            hits = _scan_shard(descr, pack, local, [(lo, hi) for _, lo, hi in mine], local_rank)
     except Exception as e:      # noqa: BLE001 -- reported below, on every rank
         failure = e
     if not all_ok(failure is None, dev):
