@@ -50,7 +50,7 @@ def test_files_that_can_only_be_read_whole(built, gbrna, tmp_path):
     assert R.Pack.read_entries([str(plain)], [1, 2], fmt="gb") is None
     odd = tmp_path / "o.fastn"
     odd.write_bytes(b">a one\nACGT\n>\nGGGG\n>c three\nTTTT\n")     # an unnamed entry: the serial reader's business
-    assert R.database_index([str(odd)]) == [12, 7, 13]
+    assert R.database_index([str(odd)]) == [12, 7, 14]
     assert R.Pack.read_entries([str(odd)], [0, 2]) is not None
     assert R.Pack.read_entries([str(odd)], [1]) is None
     assert R.Pack.read_entries([str(plain)], [3, 4], maxslen=20) is None     # -N truncation
