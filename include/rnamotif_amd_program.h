@@ -28,7 +28,7 @@ extern "C" {
 
 #define RMA_MAX_ELEMS		100		/* compile.c:49 RM_DESCR_SIZE */
 #define RMA_MAX_SITES		16
-#define RMA_MAX_EFN_SITES	8
+#define RMA_MAX_EFN_SITES	16
 #define RMA_MAX_RE		(RMA_MAX_ELEMS + 2)
 #define RMA_MAX_RE_ATOMS	64
 #define RMA_MAX_PAIRSETS	(RMA_MAX_ELEMS + RMA_MAX_SITES + 2)

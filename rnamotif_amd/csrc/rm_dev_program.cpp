@@ -601,6 +601,8 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 	out->off_pairsets = int32_t( offsetof( rmd_program_t, pairsets ) );
 	out->off_pks = int32_t( offsetof( rmd_program_t, pks ) );
 	out->off_tups = int32_t( offsetof( rmd_program_t, tups ) );
+	out->off_sites = int32_t( offsetof( rmd_program_t, sites ) );
+	out->off_efn = int32_t( offsetof( rmd_program_t, efn_sites ) );
 	out->image_bytes = int32_t( sizeof( rmd_program_t ) );
 	return 0;
 #undef FAIL
@@ -634,6 +636,14 @@ size_t rmd_make_image( const rmd_program_t *full, void *img )
 	hdr->off_tups = int32_t( n );
 	memcpy( out + n, full->tups, size_t( full->n_tups ) * sizeof( rmd_tup_t ) );
 	n += size_t( full->n_tups ) * sizeof( rmd_tup_t );
+	n = align( n, alignof( rma_efn_site_t ) );
+	hdr->off_efn = int32_t( n );
+	memcpy( out + n, full->efn_sites, size_t( full->n_efn ) * sizeof( rma_efn_site_t ) );
+	n += size_t( full->n_efn ) * sizeof( rma_efn_site_t );
+	n = align( n, alignof( rmd_site_t ) );
+	hdr->off_sites = int32_t( n );
+	memcpy( out + n, full->sites, size_t( full->n_sites ) * sizeof( rmd_site_t ) );
+	n += size_t( full->n_sites ) * sizeof( rmd_site_t );
 	n = align( n, 16 );
 	hdr->image_bytes = int32_t( n );
 	return n;

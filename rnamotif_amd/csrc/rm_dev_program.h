@@ -19,8 +19,8 @@
 #define RMD_MAX_RE	20
 #define RMD_MAX_PS	20
 #define RMD_MAX_RULES	16	// helix groups with their own mispair / pairfrac rule tables
-#define RMD_MAX_SITES	8
-#define RMD_MAX_EFN	8
+#define RMD_MAX_SITES	16	// the boundary's own limit (RMA_MAX_SITES)
+#define RMD_MAX_EFN	16
 #define RMD_MAX_PK	16	// improper (pseudoknot) helices per descriptor
 
 // position automaton of one seq= expression: state i (bit i) accepts one base
@@ -160,6 +160,7 @@ struct rmd_program_t {
 	int8_t	rowset_ps[ 4 ];
 	int32_t	n_regexes, n_rules, n_pairsets, n_pks, n_tups;
 	int32_t	off_regexes, off_rules, off_pairsets, off_pks, off_tups;
+	int32_t	off_sites, off_efn;		// (sites[ n_sites ], efn_sites[ n_efn ]: pools like the others)
 	int32_t	image_bytes;
 	// general path, records in LDS (rm_scan_hip.hip LdsGRecs): dword offset of level k's record; a
 	// level with a single alternative (rmd_elem_t::back_s) keeps its window only -- one dword,
@@ -168,14 +169,14 @@ struct rmd_program_t {
 	int32_t	n_rec_dwords;
 	int8_t	searches[ RMD_MAX_ELEMS ];
 	rmd_elem_t	lctx, rctx;
-	rmd_site_t	sites[ RMD_MAX_SITES ];
-	rma_efn_site_t	efn_sites[ RMD_MAX_EFN ];
 	rmd_elem_t	elems[ RMD_MAX_ELEMS ];
 	rmd_regex_t	regexes[ RMD_MAX_RE ];
 	rmd_rule_t	rules[ RMD_MAX_RULES ];
 	rmd_pairset_t	pairsets[ RMD_MAX_PS ];
 	rmd_pk_t	pks[ RMD_MAX_PK ];
 	rmd_tup_t	tups[ RMD_MAX_TUP ];
+	rmd_site_t	sites[ RMD_MAX_SITES ];
+	rma_efn_site_t	efn_sites[ RMD_MAX_EFN ];
 };
 
 #ifndef RMD_HD
@@ -197,6 +198,16 @@ RMD_HD const rmd_pairset_t *rmd_pairsets( const rmd_program_t *P )
 RMD_HD const rmd_pk_t *rmd_pks( const rmd_program_t *P )
 {
 	return reinterpret_cast<const rmd_pk_t *>( reinterpret_cast<const char *>( P ) + P->off_pks );
+}
+
+RMD_HD const rmd_site_t *rmd_sites( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rmd_site_t *>( reinterpret_cast<const char *>( P ) + P->off_sites );
+}
+
+RMD_HD const rma_efn_site_t *rmd_efn_sites( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rma_efn_site_t *>( reinterpret_cast<const char *>( P ) + P->off_efn );
 }
 
 RMD_HD const rmd_tup_t *rmd_tups( const rmd_program_t *P )

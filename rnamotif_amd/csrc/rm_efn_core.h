@@ -512,7 +512,7 @@ RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const
 	c.P = P;
 	c.w = w;
 	c.sq = sq;
-	if( !c.setup( P->efn_sites[ k ] ) )
+	if( !c.setup( rmd_efn_sites( P )[ k ] ) )
 		return RME_INF;
 	if( bpbuf != nullptr && c.len <= cache )
 		c.fill_cache( bpbuf, bcbuf );

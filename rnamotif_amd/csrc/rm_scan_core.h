@@ -551,7 +551,7 @@ template< class SQ >
 RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const SQ &sq )	// chk_sites :1758
 {
 	for( int s = 0; s < P->n_sites; s++ ){
-		const rmd_site_t	&si = P->sites[ s ];
+		const rmd_site_t	&si = rmd_sites( P )[ s ];
 		int	b[ 4 ] = { 0, 0, 0, 0 };
 		for( int k = 0; k < si.n_pos; k++ ){
 			int	d = si.elem[ k ], pos;

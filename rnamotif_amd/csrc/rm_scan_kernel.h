@@ -1243,7 +1243,7 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 		int32_t	*w = hits + h * gP->hit_stride;
 		DevSeq	sq{ db, db.base_off[ w[ 0 ] ], db.slen[ w[ 0 ] ], w[ 1 ] };
 		for( int k = 0; k < gP->n_efn; k++ ){
-			if( gP->efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
+			if( rmd_efn_sites( gP )[ k ].kind == RMA_EFN_KIND_EFN2 )
 				w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy( gP, e2, &sq, w, k, bpbuf, bcbuf, EFN_CACHE ) : RME2_INF;
 			else if( g16 != nullptr )
 				w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k, bpbuf, bcbuf, EFN_CACHE );

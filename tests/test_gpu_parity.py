@@ -938,3 +938,33 @@ def test_random_descriptors_with_energy_sites(built, tmp_path, seed):
     got = sc.scan(sc.database([s]))
     assert got.shape == want.shape, text
     assert np.array_equal(got, want), text
+
+
+def test_sixteen_sites_and_energy_calls(built, tmp_path, gbrna):
+    """The boundary's own limits -- 16 sites, 16 efn()/efn2() calls in the score section (8 each until
+    round 2) -- against the oracle: a cloverleaf-like descriptor with 12 sites and 10 energy calls."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    text = ("parms\n\twc += gu;\ndescr\n"
+            "\th5(tag='a',minlen=5,maxlen=7)\n\t\tss(minlen=2,maxlen=4)\n"
+            "\t\th5(tag='b',minlen=3,maxlen=4)\n\t\t\tss(minlen=4,maxlen=9)\n\t\th3(tag='b')\n"
+            "\t\tss(minlen=1,maxlen=3)\n"
+            "\t\th5(tag='c',minlen=3,maxlen=5)\n\t\t\tss(minlen=5,maxlen=8)\n\t\th3(tag='c')\n"
+            "\t\tss(minlen=2,maxlen=6)\n\th3(tag='a')\n"
+            "sites\n" +
+            "".join("\th5(tag='%s',pos=%d):h3(tag='%s',pos=$-%d) in { 'a:u', 'u:a', 'g:c', 'c:g', 'g:u', 'u:g' }\n" % (t, p, t, p - 1)
+                    for t, n in (("a", 5), ("b", 3), ("c", 3)) for p in range(1, n + 1)) +
+            "\th5(tag='a',pos=1):h3(tag='a',pos=$) in { 'g:c', 'c:g', 'a:u', 'u:a' }\n"
+            "score\n\t{ SCORE = sprintf( '" + " ".join(["%6.2f"] * 10) + "', " +
+            ", ".join(["efn( h5['a'], h3['a'] )", "efn2( h5['a'], h3['a'] )", "efn( h5['b'], h3['b'] )", "efn2( h5['b'], h3['b'] )",
+                       "efn( h5['c'], h3['c'] )", "efn2( h5['c'], h3['c'] )", "efn( h5['b'], h3['c'] )", "efn2( h5['b'], h3['c'] )",
+                       "efn( h5['a'], h3['c'] )", "efn2( h5['b'], h3['a'] )"]) + " ); }\n")
+    p = tmp_path / "many.descr"
+    p.write_text(text)
+    d = R.Descriptor(["-descr", str(p)])
+    assert d.n_efn_sites == 10
+    seqs = [r[2] for r in R.read_fasta(gbrna)[:1200]]
+    want = oracle_scan(d, seqs)
+    sc = R.Scanner(d)
+    got = sc.scan(sc.database(seqs))
+    assert want.shape[0] > 20 and got.shape == want.shape and np.array_equal(got, want)
