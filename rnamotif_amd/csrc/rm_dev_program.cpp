@@ -329,6 +329,33 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		e.tup = int8_t( n_tups++ );
 	}
 	out->n_tups = n_tups;
+	// a 4-plex at the head of the search list: what pass A can ask of its inner strands (rmd_q1filter_t)
+	memset( &out->q1f, 0, sizeof( out->q1f ) );
+	{
+		const rmd_elem_t	&e0 = out->elems[ p->searches[ 0 ] ];
+		if( e0.type == RMA_T_Q1 && e0.tup >= 0 && e0.n_mates == 3 && e0.minlen >= 1 && e0.minlen <= 12 ){
+			const rmd_elem_t	&e1 = out->elems[ e0.mates[ 0 ] ], &e2 = out->elems[ e0.mates[ 1 ] ];
+			const rmd_tup_t	&u = out->tups[ e0.tup ];
+			rmd_q1filter_t	&f = out->q1f;
+			for( int i = 0; i < 25; i++ )
+				f.m2 |= int8_t( u.q2[ i ] );
+			for( int i = 0; i < 125; i++ )
+				f.m3 |= int8_t( u.q3[ i ] );
+			f.first5 = ( e1.ends & RMA_5PAIRED ) != 0;
+			f.nmin = int8_t( e0.minlen );
+			int	bad = 0;
+			for( int hl = e0.minlen; hl <= e0.maxlen && hl <= RMD_MAX_HLEN; hl++ )
+				bad = std::max( bad, int( out->rules[ e1.rule ].tq_mplim[ hl ] ) );
+			f.badmax = int8_t( std::min( bad, 3 ) );
+			const int	big = 1 << 14;
+			f.a_lo = int16_t( e0.minlen + e0.minilen );
+			f.a_hi = int16_t( e0.maxilen < big && e0.maxlen < big ? e0.maxlen - 1 + e0.maxilen : -1 );
+			f.b_hi = int16_t( e0.minlen + e2.minilen );
+			f.b_lo = int16_t( e2.maxilen < big && e0.maxlen < big ? e0.maxlen - 1 + e2.maxilen : -1 );
+			// (reach of a few words at most: what lies farther is left to the search)
+			f.on = f.a_hi >= f.a_lo && f.b_lo >= f.b_hi && f.a_hi - f.a_lo < 64 && f.b_lo - f.b_hi < 64 && f.a_lo < 4000 && f.b_hi < 4000;
+		}
+	}
 	// pair row sets: one per distinct pair table of the helices that are matched with
 	// match_wchlx() at a search level and whose first-pairs rule fits the bit-parallel test
 	out->n_rowsets = 0;

@@ -129,6 +129,20 @@ struct rmd_site_t {
 	int16_t	offset[ 4 ];
 };
 
+// Pre-filter of a 4-plex that heads the search list (rm_scan_kernel.h, pass A): what its second and
+// third strands demand of the bases alone.  A quad can only hold where the second strand's base is one
+// that some quad of the pair set has in second place (m2), likewise the third (m3); match_4plex()
+// (find_motif.c:1234-1290) gives up at the first quad when the 5' end must pair and lets at most
+// tq_mplim further quads fail, so a strand can stand at a position only if its first base is in the
+// set (first5) and at most badmax of its next nmin - 1 bases are not.  Start positions whose second
+// strand finds no such place within reach (a_lo .. a_hi bases after the start), and end positions whose
+// third strand finds none (b_hi .. b_lo bases before the end), are not queued: necessary conditions,
+// the candidates stay what they are.  on = 0: no such filter (another first element, masks unknown).
+struct rmd_q1filter_t {
+	int8_t	on, m2, m3, first5, nmin, badmax;
+	int16_t	a_lo, a_hi, b_hi, b_lo;		// (a_hi / b_lo < 0: unbounded)
+};
+
 struct rmd_program_t {
 	int32_t	n_elems, n_searches;
 	int32_t	dminlen, w_winsize;	// min( dmaxlen, windowsize )
@@ -160,7 +174,8 @@ struct rmd_program_t {
 	int8_t	rowset_ps[ 4 ];
 	int32_t	n_regexes, n_rules, n_pairsets, n_pks, n_tups;
 	int32_t	off_regexes, off_rules, off_pairsets, off_pks, off_tups;
-	int32_t	off_sites, off_efn;		// (sites[ n_sites ], efn_sites[ n_efn ]: pools like the others)
+	int32_t	off_sites, off_efn;
+	rmd_q1filter_t	q1f;		// (sites[ n_sites ], efn_sites[ n_efn ]: pools like the others)
 	int32_t	image_bytes;
 	// general path, records in LDS (rm_scan_hip.hip LdsGRecs): dword offset of level k's record; a
 	// level with a single alternative (rmd_elem_t::back_s) keeps its window only -- one dword,

@@ -490,7 +490,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// bit vectors of a slot: where the best literal occurs, then five pair rows per row set (the lean
 	// instance keeps one set, the first element's; the general one a set per pair table its helices use)
 	const int	n_rs = LEAN ? 1 : P->n_rowsets;
-	const int	n_vec = 1 + 5 * n_rs;
+	// (a 4-plex at the head of the search list: four more, rmd_q1filter_t)
+	const bool	q1f = !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on && !( dbg & 8192 );
+	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? 4 : 0 );
 	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
@@ -726,6 +728,54 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			SLOT_SYNC();
 			PHASE( 2 );
 		}
+		// Strand filter of a leading 4-plex (rmd_q1filter_t): G2 / G3 -- where a base stands that some quad
+		// has in second / third place -- then A -- start positions from which a second strand can be reached --
+		// and B -- end positions before which a third strand can stand.  Bit q + 64 of a vector is tile position q.
+		unsigned long long	*const xv = pb + 5 * n_rs * pb_words;
+		if( q1f ){
+			const rmd_q1filter_t	F = P->q1f;
+			const int	n_valid = p_to - p_lo, vec_bits = vec_words * 64;
+			for( int base = ubase; base < vec_words * 64; base += UNIT ){
+				const int	q = base + lane_id - 64;
+				const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
+				const unsigned long long	g2 = __ballot( code < 5 && ( ( F.m2 >> code ) & 1 ) );
+				const unsigned long long	g3 = __ballot( code < 5 && ( ( F.m3 >> code ) & 1 ) );
+				if( lane_id == 0 ){
+					xv[ base >> 6 ] = g2;
+					xv[ pb_words + ( base >> 6 ) ] = g3;
+				}
+			}
+			SLOT_SYNC();
+			// 64 positions from bit x on: can the strand stand there?  dir +1: second strand, from its start
+			// onwards; -1: third strand, from its end backwards.  Bits the vectors do not hold: undecided, kept.
+			auto	stand = [ & ]( const unsigned long long *gv, int x, int dir ) -> unsigned long long {
+				if( x - F.nmin < 0 || x + F.nmin + 96 > vec_bits )
+					return ~0ull;
+				unsigned long long	c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+				for( int q = 1; q < F.nmin; q++ ){
+					const unsigned long long	mis = ~bits64( gv, x + dir * q );
+					c4 |= c3 & mis;
+					c3 |= c2 & mis;
+					c2 |= c1 & mis;
+					c1 |= mis;
+				}
+				unsigned long long	ok = ~( F.badmax == 0 ? c1 : F.badmax == 1 ? c2 : F.badmax == 2 ? c3 : c4 );
+				if( F.first5 )
+					ok &= bits64( gv, x );
+				return ok;
+			};
+			for( int wi = utid; wi < vec_words; wi += UNIT ){
+				const int	x = wi * 64;
+				unsigned long long	a = 0, b = 0;
+				for( int d = F.a_lo; d <= F.a_hi && ~a; d++ )
+					a |= stand( xv, x + d, 1 );
+				for( int d = F.b_hi; d <= F.b_lo && ~b; d++ )
+					b |= stand( xv + pb_words, x - d, -1 );
+				xv[ 2 * pb_words + wi ] = a;
+				xv[ 3 * pb_words + wi ] = b;
+			}
+			SLOT_SYNC();
+		}
 		if( bitpar ){
 			const int	hl0 = e0.minlen;
 			// superset of match_wchlx's rule (find_motif.c:1010-1033,1065-1080): at most mplim
@@ -865,14 +915,26 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 				const int	rel = rel0;
 				const int	szero = z0 + rel;
-				const bool	valid = valid0;
+				bool	valid = valid0;
+				if( q1f && valid ){
+					// no place within reach for the 4-plex' second strand: nothing starts here
+					const int	bq = szero - p_lo + 64;
+					valid = ( xv[ 2 * pb_words + ( bq >> 6 ) ] >> ( bq & 63 ) ) & 1;
+				}
 				int	hi = 0, lo = 1;
 				if( valid )
 					rmd_level0_range( P, szero, slen, &hi, &lo );
 				for( int r0 = 0; r0 < n_rank; r0 += 64 ){
 					unsigned long long	W = 0;
-					if( valid && r0 <= hi - lo )
+					if( valid && r0 <= hi - lo ){
 						W = win( szero, hi, r0, lo );
+						if( q1f && W ){
+							// ... and end positions before which no third strand can stand (bit i: end hi - r0 - 63 + i)
+							const int	bq = hi - r0 - 63 - p_lo + 64;
+							if( bq >= 0 && bq + 96 <= vec_words * 64 )
+								W &= bits64( xv + 3 * pb_words, bq );
+						}
+					}
 					while( __ballot( W != 0 ) ){
 						const bool	has = W != 0;
 						const int	i = has ? __ffsll( W ) - 1 : 0;

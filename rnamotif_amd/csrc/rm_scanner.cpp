@@ -311,7 +311,8 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1 )
 {
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	// (bit vectors of a tile: the literal's, five per pair-row set, four of a leading 4-plex' strand filter)
+	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? 4 : 0 ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;
@@ -462,9 +463,13 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		sc->qcap = 512 / per_wave < 128 ? 128 : 512 / per_wave;
 		sc->tile_t = 1024;
 		bool	found = false;
-		for( int wg = GENERAL_WAVES( sc->kinds & RMD_KIND_TQ ); wg >= 1 && !found; wg-- ){
+		// (descriptors with triplexes / 4-plexes: two workgroups per SIMD on tiles of three thousand positions
+		// rather than three on a thousand -- a tile's second round then has a few dozen continuations for
+		// its lanes instead of five: qu+tr 19.6 -> 16.7 ms; pk1 and pk_j1+2 are best at 2048, four per SIMD)
+		const int	wg0 = ( sc->kinds & RMD_KIND_TQ ) ? 2 : GENERAL_WAVES( 0 );
+		for( int wg = wg0; wg >= 1 && !found; wg-- ){
 			const size_t	budget = ( 160 * 1024 ) / ( wg * per_wave ) - ( per_wave > 1 ? 1024 : 2560 );	// (static __shared__ -- the pre-filter's wave buffers -- and allocation granules)
-			for( int t = 8192 / per_wave; t >= ( wg > 1 ? 3072 / per_wave : 1024 / per_wave ); t -= 256 )
+			for( int t = ( per_wave > 1 ? 4096 : 8192 ); t >= ( wg > 1 ? 3072 / per_wave : 1024 / per_wave ); t -= 256 )
 				if( search_lds_bytes( sc->prog_bytes, sc->dprog, t, false, sc->qcap ) <= budget ){
 					sc->tile_t = t;
 					found = true;
