@@ -354,6 +354,42 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			f.b_lo = int16_t( e2.maxilen < big && e0.maxlen < big ? e0.maxlen - 1 + e2.maxilen : -1 );
 			// (reach of a few words at most: what lies farther is left to the search)
 			f.on = f.a_hi >= f.a_lo && f.b_lo >= f.b_hi && f.a_hi - f.a_lo < 64 && f.b_lo - f.b_hi < 64 && f.a_lo < 4000 && f.b_hi < 4000;
+			// ... followed by a triplex, with at most one single strand in between?
+			int	ss_lo = 0, ss_hi = 0, ts = e0.next_s;
+			if( f.on && ts >= 0 && out->elems[ p->searches[ ts ] ].type == RMA_T_SS ){
+				const rmd_elem_t	&ss = out->elems[ p->searches[ ts ] ];
+				ss_lo = ss.minlen;
+				ss_hi = ss.maxlen;
+				ts = ss.next_s;
+			}
+			if( f.on && ts >= 0 && ss_hi < big && out->elems[ p->searches[ ts ] ].type == RMA_T_T1 ){
+				const rmd_elem_t	&t = out->elems[ p->searches[ ts ] ];
+				if( t.tup >= 0 && t.n_scopes == 3 && t.minlen >= 1 && t.minlen <= 12 && t.maxlen < big &&
+					t.maxilen < big && out->elems[ t.scopes[ 1 ] ].maxilen < big ){
+					const rmd_elem_t	&t2 = out->elems[ t.scopes[ 1 ] ];
+					const rmd_tup_t	&tu = out->tups[ t.tup ];
+					for( int b1 = 0; b1 < 5; b1++ )
+						for( int b3 = 0; b3 < 5; b3++ )
+							if( tu.t2[ b1 * 5 + b3 ] ){
+								f.tm1 |= int8_t( 1 << b1 );
+								f.tm3 |= int8_t( 1 << b3 );
+								f.tm2 |= int8_t( tu.t2[ b1 * 5 + b3 ] );
+							}
+					f.tfirst5 = ( t.ends & RMA_5PAIRED ) != 0;
+					f.tnmin = int8_t( t.minlen );
+					int	tb = 0;
+					for( int hl = t.minlen; hl <= t.maxlen && hl <= RMD_MAX_HLEN; hl++ )
+						tb = std::max( tb, int( out->rules[ t.rule ].tq_mplim[ hl ] ) );
+					f.tbad = int8_t( std::min( tb, 3 ) );
+					f.f_lo = int16_t( 1 + ss_lo );
+					f.f_hi = int16_t( 1 + ss_hi );
+					f.r1_lo = int16_t( 2 * t.minlen + t.minilen - 1 );
+					f.r1_hi = int16_t( 2 * t.maxlen + t.maxilen - 1 );
+					f.r2_lo = int16_t( 1 + t2.minilen );
+					f.r2_hi = int16_t( 1 + t2.maxilen );
+					f.t_on = f.f_hi - f.f_lo < 64 && f.r1_hi - f.r1_lo < 64 && f.r2_hi - f.r2_lo < 64 && f.r1_hi < 2000;
+				}
+			}
 		}
 	}
 	// pair row sets: one per distinct pair table of the helices that are matched with

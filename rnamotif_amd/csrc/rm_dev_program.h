@@ -138,9 +138,17 @@ struct rmd_site_t {
 // strand finds no such place within reach (a_lo .. a_hi bases after the start), and end positions whose
 // third strand finds none (b_hi .. b_lo bases before the end), are not queued: necessary conditions,
 // the candidates stay what they are.  on = 0: no such filter (another first element, masks unknown).
+// t_on: the 4-plex' group is followed (after at most one single strand) by a triplex -- qu+tr.descr.
+// The same argument along the triplex' three strands (match_triplex, find_motif.c:1183-1232: first
+// triple of a strand's first base, at most tq_mplim further triples may fail): a start u of its first
+// strand is feasible if the strand can stand there and a second strand can END v - u in [r1_lo, r1_hi]
+// later with a third one STARTING w - v in [r2_lo, r2_hi] after that; an end position e of the 4-plex'
+// group is worth queueing only if some feasible u lies u - e in [f_lo, f_hi] behind it.
 struct rmd_q1filter_t {
 	int8_t	on, m2, m3, first5, nmin, badmax;
+	int8_t	t_on, tm1, tm2, tm3, tfirst5, tnmin, tbad, pad_;
 	int16_t	a_lo, a_hi, b_hi, b_lo;		// (a_hi / b_lo < 0: unbounded)
+	int16_t	f_lo, f_hi, r1_lo, r1_hi, r2_lo, r2_hi;
 };
 
 struct rmd_program_t {

@@ -492,7 +492,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const int	n_rs = LEAN ? 1 : P->n_rowsets;
 	// (a 4-plex at the head of the search list: four more, rmd_q1filter_t)
 	const bool	q1f = !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on && !( dbg & 8192 );
-	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? 4 : 0 );
+	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 );
 	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
@@ -734,6 +734,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		unsigned long long	*const xv = pb + 5 * n_rs * pb_words;
 		if( q1f ){
 			const rmd_q1filter_t	F = P->q1f;
+			const bool	tri = F.t_on && !( dbg & 16384 );
 			const int	n_valid = p_to - p_lo, vec_bits = vec_words * 64;
 			for( int base = ubase; base < vec_words * 64; base += UNIT ){
 				const int	q = base + lane_id - 64;
@@ -744,37 +745,78 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					xv[ base >> 6 ] = g2;
 					xv[ pb_words + ( base >> 6 ) ] = g3;
 				}
+				if( tri ){
+					const unsigned long long	t1 = __ballot( code < 5 && ( ( F.tm1 >> code ) & 1 ) );
+					const unsigned long long	t2 = __ballot( code < 5 && ( ( F.tm2 >> code ) & 1 ) );
+					const unsigned long long	t3 = __ballot( code < 5 && ( ( F.tm3 >> code ) & 1 ) );
+					if( lane_id == 0 ){
+						xv[ 4 * pb_words + ( base >> 6 ) ] = t1;
+						xv[ 5 * pb_words + ( base >> 6 ) ] = t2;
+						xv[ 6 * pb_words + ( base >> 6 ) ] = t3;
+					}
+				}
 			}
 			SLOT_SYNC();
-			// 64 positions from bit x on: can the strand stand there?  dir +1: second strand, from its start
-			// onwards; -1: third strand, from its end backwards.  Bits the vectors do not hold: undecided, kept.
-			auto	stand = [ & ]( const unsigned long long *gv, int x, int dir ) -> unsigned long long {
-				if( x - F.nmin < 0 || x + F.nmin + 96 > vec_bits )
+			// 64 positions from bit x on: can a strand stand there?  dir +1: read from its start onwards;
+			// -1: from its end backwards.  Bits the vectors do not hold: undecided, kept.
+			auto	stand = [ & ]( const unsigned long long *gv, int x, int dir, int nmin, int badmax, bool first5 ) -> unsigned long long {
+				if( x - nmin < 0 || x + nmin + 96 > vec_bits )
 					return ~0ull;
 				unsigned long long	c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-				for( int q = 1; q < F.nmin; q++ ){
+				for( int q = 1; q < nmin; q++ ){
 					const unsigned long long	mis = ~bits64( gv, x + dir * q );
 					c4 |= c3 & mis;
 					c3 |= c2 & mis;
 					c2 |= c1 & mis;
 					c1 |= mis;
 				}
-				unsigned long long	ok = ~( F.badmax == 0 ? c1 : F.badmax == 1 ? c2 : F.badmax == 2 ? c3 : c4 );
-				if( F.first5 )
+				unsigned long long	ok = ~( badmax == 0 ? c1 : badmax == 1 ? c2 : badmax == 2 ? c3 : c4 );
+				if( first5 )
 					ok &= bits64( gv, x );
 				return ok;
+			};
+			// 64 bits of a finished vector from bit x on (outside it: undecided)
+			auto	peek = [ & ]( const unsigned long long *v, int x ) -> unsigned long long {
+				return x >= 0 && x + 96 <= vec_bits ? bits64( v, x ) : ~0ull;
 			};
 			for( int wi = utid; wi < vec_words; wi += UNIT ){
 				const int	x = wi * 64;
 				unsigned long long	a = 0, b = 0;
 				for( int d = F.a_lo; d <= F.a_hi && ~a; d++ )
-					a |= stand( xv, x + d, 1 );
+					a |= stand( xv, x + d, 1, F.nmin, F.badmax, F.first5 );
 				for( int d = F.b_hi; d <= F.b_lo && ~b; d++ )
-					b |= stand( xv + pb_words, x - d, -1 );
+					b |= stand( xv + pb_words, x - d, -1, F.nmin, F.badmax, F.first5 );
 				xv[ 2 * pb_words + wi ] = a;
 				xv[ 3 * pb_words + wi ] = b;
+				if( tri ){
+					// ends of a second strand of the triplex with a third one within reach behind them
+					unsigned long long	r2 = 0;
+					for( int d = F.r2_lo; d <= F.r2_hi && ~r2; d++ )
+						r2 |= stand( xv + 6 * pb_words, x + d, 1, F.tnmin, F.tbad, F.tfirst5 );
+					xv[ 7 * pb_words + wi ] = r2 & stand( xv + 5 * pb_words, x, -1, F.tnmin, F.tbad, F.tfirst5 );
+				}
 			}
 			SLOT_SYNC();
+			if( tri ){
+				// starts of a first strand with such a second one within reach ...
+				for( int wi = utid; wi < vec_words; wi += UNIT ){
+					const int	x = wi * 64;
+					unsigned long long	r1 = 0;
+					for( int d = F.r1_lo; d <= F.r1_hi && ~r1; d++ )
+						r1 |= peek( xv + 7 * pb_words, x + d );
+					xv[ 8 * pb_words + wi ] = r1 & stand( xv + 4 * pb_words, x, 1, F.tnmin, F.tbad, F.tfirst5 );
+				}
+				SLOT_SYNC();
+				// ... and the end positions of the 4-plex' group that have one of those behind them
+				for( int wi = utid; wi < vec_words; wi += UNIT ){
+					const int	x = wi * 64;
+					unsigned long long	f = 0;
+					for( int d = F.f_lo; d <= F.f_hi && ~f; d++ )
+						f |= peek( xv + 8 * pb_words, x + d );
+					xv[ 3 * pb_words + wi ] &= f;
+				}
+				SLOT_SYNC();
+			}
 		}
 		if( bitpar ){
 			const int	hl0 = e0.minlen;

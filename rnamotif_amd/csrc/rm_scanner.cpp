@@ -311,8 +311,8 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1 )
 {
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
-	// (bit vectors of a tile: the literal's, five per pair-row set, four of a leading 4-plex' strand filter)
-	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? 4 : 0 ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	// (bit vectors of a tile: the literal's, five per pair-row set, four of a leading 4-plex' strand filter, five more when a triplex follows it)
+	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? ( dp.q1f.t_on ? 9 : 4 ) : 0 ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;

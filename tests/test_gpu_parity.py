@@ -968,3 +968,42 @@ def test_sixteen_sites_and_energy_calls(built, tmp_path, gbrna):
     sc = R.Scanner(d)
     got = sc.scan(sc.database(seqs))
     assert want.shape[0] > 20 and got.shape == want.shape and np.array_equal(got, want)
+
+
+Q1_VARIANTS = [
+    # (4-plex attributes, what follows)
+    ("minlen=3, maxlen=5, mispair=1", "\tss( minlen=3, maxlen=10 )\n\tt1( tag='2', minlen=4, maxlen=7, mispair=1 )\n\t\tss( minlen=3, maxlen=10 )\n\tt2( tag='2' )\n\t\tss( minlen=3, maxlen=10 )\n\tt3( tag='2' )\n"),
+    ("minlen=2, maxlen=4, mispair=0", "\tt1( tag='2', minlen=3, maxlen=4, mispair=0 )\n\t\tss( minlen=2, maxlen=6 )\n\tt2( tag='2' )\n\t\tss( minlen=2, maxlen=6 )\n\tt3( tag='2' )\n"),
+    ("minlen=3, maxlen=3, mispair=2, ends='mm'", "\tss( minlen=0, maxlen=4 )\n\tt1( tag='2', minlen=3, maxlen=5, mispair=2, ends='mm' )\n\t\tss( minlen=1, maxlen=5 )\n\tt2( tag='2' )\n\t\tss( minlen=1, maxlen=5 )\n\tt3( tag='2' )\n"),
+    ("minlen=2, maxlen=3, mispair=1", "\tss( minlen=2, maxlen=5 )\n\th5( minlen=3, maxlen=4 )\n\t\tss( minlen=3, maxlen=6 )\n\th3\n"),
+    ("minlen=3, maxlen=4, mispair=1", ""),
+]
+
+
+@pytest.mark.parametrize("variant", range(len(Q1_VARIANTS)))
+def test_leading_4plex_strand_filter(built, tmp_path, variant):
+    """A 4-plex at the head of the search list takes the pre-filter's strand filter (rmd_q1filter_t),
+    with the look-ahead along a triplex that follows it where there is one: same records as the oracle
+    on G-rich sequence (where 4-plexes and triplexes do occur), for several shapes of the two."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    attrs, after = Q1_VARIANTS[variant]
+    text = ("descr\n\tq1( tag='1', %s )\n\t\tss( minlen=2, maxlen=6 )\n\tq2( tag='1' )\n\t\tss( minlen=2, maxlen=6 )\n"
+            "\tq3( tag='1' )\n\t\tss( minlen=2, maxlen=6 )\n\tq4( tag='1' )\n" % attrs) + after
+    p = tmp_path / "q.descr"
+    p.write_text(text)
+    d = R.Descriptor(["-descr", str(p)])
+    rng = np.random.default_rng(40 + variant)
+    lut = np.frombuffer(b"acgtn", dtype=np.uint8)
+    seqs = [lut[rng.choice(5, size=n, p=pr)].tobytes()
+            for n, pr in ((60_000, [.15, .1, .55, .2, 0]), (20_003, [.3, .1, .3, .3, 0]), (9_000, [.1, .1, .5, .28, .02]), (70, [.1, .1, .6, .2, 0]))]
+    want = oracle_scan(d, seqs)
+    sc = R.Scanner(d)
+    got = sc.scan(sc.database(seqs))
+    assert want.shape[0] > 0 or variant == 1, "the sequence should hold some of these"
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # ... and with the filter switched off (dbg bits 8192, 16384: the launch shape stays)
+    for bits in (8192, 16384):
+        sc.set_option("dbg", bits)
+        again = sc.scan(sc.database(seqs))
+        assert np.array_equal(again, want)
