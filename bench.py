@@ -325,10 +325,13 @@ def main():
     def new_db(wait):
         return sc.database_from_pack(pack, wait=wait)
 
-    def scan_all(db):
-        """Every descriptor over db, kernels side by side; the records of all of them on rank 0."""
+    def scan_begin(db):
+        """Every descriptor's search kernel over db on its way, side by side on the scanners' streams."""
         for s_ in scs:
             s_.scan_begin(db)
+
+    def scan_end():
+        """Energies, ordering, the records of all descriptors on rank 0; their number."""
         n = 0
         for d_, s_ in zip(descrs, scs):
             if world == 1:
@@ -347,15 +350,19 @@ def main():
     state = {"cur": new_db(True)}
 
     def step_h2d():
-        """Upload of the next batch under the scan of this one; this one's block of HBM back to the pool."""
+        """The kernels of this batch are launched, then the next batch's upload is put on the upload stream
+        (its host side runs under the kernels), then this batch is finished; its block of HBM goes back to
+        the pool."""
+        scan_begin(state["cur"])
         nxt = new_db(False)
-        n = scan_all(state["cur"])
+        n = scan_end()
         state["cur"].close()
         state["cur"] = nxt
         return n
 
     def step_resident():
-        return scan_all(state["cur"])
+        scan_begin(state["cur"])
+        return scan_end()
 
     step = step_resident if args.resident else step_h2d
 
