@@ -2,6 +2,7 @@
 // (see rm_dev_program.h).  Host code.
 #include "rm_dev_program.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -550,6 +551,56 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 				d->tail_pre_min = int16_t( mn );
 				d->tail_pre_max = ( unb || mx >= 30000 ) ? int16_t( -1 ) : int16_t( mx );
 			}
+		}
+	}
+	// the look-ahead chain of the first element's interior (rmd_chain_t)
+	memset( &out->chain, 0, sizeof( out->chain ) );
+	if( out->lean_ok ){
+		const rmd_elem_t	&e0 = out->elems[ p->searches[ 0 ] ];
+		rmd_chain_t	&ch = out->chain;
+		if( e0.type == RMA_T_H5 && e0.proper && e0.inner_s >= 0 && e0.rows == 0 && e0.minlen >= 1 && e0.maxlen < 1000 ){
+			ch.s_lo = int16_t( e0.minlen );
+			ch.s_hi = int16_t( e0.maxlen );
+			bool	any_leaf = false;
+			for( int s = e0.inner_s; s >= 0 && ch.n < RMD_MAX_CHAIN; s = out->elems[ p->searches[ s ] ].next_s ){
+				const rmd_elem_t	&g = out->elems[ p->searches[ s ] ];
+				if( g.maxglen == RMA_UNBOUNDED || g.maxglen >= 2000 )
+					break;		// (what lies behind a group of any length is not pinned down by the start)
+				rmd_chain_sib_t	&sb = ch.sib[ ch.n++ ];
+				sb.len_lo = int16_t( g.minglen );
+				sb.len_hi = int16_t( g.maxglen );
+				if( g.type == RMA_T_H5 && g.proper && g.pairset == e0.pairset && g.mplim == 0 && !g.pfrac &&
+					( g.ends & RMA_5PAIRED ) && ( g.ends & RMA_3PAIRED ) &&
+					g.minlen >= 2 && g.minlen <= 16 && g.maxlen < 64 && g.inner_s >= 0 && g.maxilen != RMA_UNBOUNDED && g.maxilen - g.minilen < 32 ){
+					// a stem-loop: nothing but single strands inside
+					bool	only_ss = true;
+					for( int t = g.inner_s; t >= 0; t = out->elems[ p->searches[ t ] ].next_s )
+						only_ss = only_ss && out->elems[ p->searches[ t ] ].type == RMA_T_SS;
+					// ... and worth its price: a stem-loop that most positions could start (a short helix with many
+					// loop lengths: trna.descr's D arm, 3 pairs and 8 loop lengths, stands at one position in two)
+					// costs a pass over the tile per loop length and filters little
+					double	p_pair = 0;
+					{
+						const uint32_t	m2 = out->pairsets[ e0.pairset ].mat2;
+						for( int a = 0; a < 4; a++ )
+							for( int b = 0; b < 4; b++ )
+								p_pair += ( ( m2 >> ( a * 5 + b ) ) & 1 ) / 16.0;
+					}
+					const double	p_leaf = ( g.maxlen - g.minlen + 1 ) * ( g.maxilen - g.minilen + 1 ) * std::pow( p_pair, g.minlen );
+					if( only_ss && p_leaf <= 0.25 ){
+						sb.leaf = 1;
+						sb.hmin = int8_t( g.minlen );
+						sb.tmax = int16_t( g.maxlen - g.minlen );
+						sb.lmin = int16_t( g.minilen );
+						sb.lmax = int16_t( g.maxilen );
+						any_leaf = true;
+					}
+				}
+			}
+			// (drop groups behind the last stem-loop: they say nothing)
+			while( ch.n > 0 && !ch.sib[ ch.n - 1 ].leaf )
+				ch.n--;
+			ch.on = any_leaf && ch.n > 0;
 		}
 	}
 	for( int s = 0; s < p->n_sites; s++ ){

@@ -129,6 +129,30 @@ struct rmd_site_t {
 	int16_t	offset[ 4 ];
 };
 
+// Look-ahead of the lean pre-filter (rm_scan_kernel.h, pass A): what the interior of the first search
+// element -- a proper helix, the outer stem of a cloverleaf or of any nested motif -- needs to hold at
+// all.  Its interior is a chain of groups: single strands, and helices with their own interiors.  A
+// helix whose interior is single strands only (a stem-loop: "leaf") can start at a position only if
+// its innermost hmin pairs are there for one of the loop lengths it allows -- a bit per position,
+// computed for the whole tile from the pair rows by shifted ANDs -- and a group can start where the
+// next group can start one of its lengths later.  Chained from the last group back to the first, this
+// says for every start position of the motif whether its interior can exist at all; positions where it
+// cannot are not searched (for trna.descr: 19 in 20).  Necessary conditions only: helices that allow
+// mispairs, and everything that is not a stem-loop, count as "any".
+#define RMD_MAX_CHAIN	8
+struct rmd_chain_sib_t {
+	int8_t	leaf;			// 1: stem-loop on the first element's pair table, no mispairs
+	int8_t	hmin;			// leaf: pairs of its shortest helix
+	int16_t	tmax;			// leaf: longest minus shortest helix (the core of hmin pairs lies 0 .. tmax in)
+	int16_t	lmin, lmax;		// leaf: loop lengths
+	int16_t	len_lo, len_hi;		// total length of the group
+};
+struct rmd_chain_t {
+	int8_t	on, n;
+	int16_t	s_lo, s_hi;		// first group starts s_lo .. s_hi after the start position (the outer helix' lengths)
+	rmd_chain_sib_t	sib[ RMD_MAX_CHAIN ];
+};
+
 // Pre-filter of a 4-plex that heads the search list (rm_scan_kernel.h, pass A): what its second and
 // third strands demand of the bases alone.  A quad can only hold where the second strand's base is one
 // that some quad of the pair set has in second place (m2), likewise the third (m3); match_4plex()
@@ -183,7 +207,8 @@ struct rmd_program_t {
 	int32_t	n_regexes, n_rules, n_pairsets, n_pks, n_tups;
 	int32_t	off_regexes, off_rules, off_pairsets, off_pks, off_tups;
 	int32_t	off_sites, off_efn;
-	rmd_q1filter_t	q1f;		// (sites[ n_sites ], efn_sites[ n_efn ]: pools like the others)
+	rmd_q1filter_t	q1f;
+	rmd_chain_t	chain;		// (sites[ n_sites ], efn_sites[ n_efn ]: pools like the others)
 	int32_t	image_bytes;
 	// general path, records in LDS (rm_scan_hip.hip LdsGRecs): dword offset of level k's record; a
 	// level with a single alternative (rmd_elem_t::back_s) keeps its window only -- one dword,

@@ -492,10 +492,16 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const int	n_rs = LEAN ? 1 : P->n_rowsets;
 	// (a 4-plex at the head of the search list: four more, rmd_q1filter_t)
 	const bool	q1f = !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on && !( dbg & 8192 );
-	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 );
+	// (lean, one tile per pass, with a look-ahead chain: eight more, rmd_chain_t)
+	const bool	chain_on = LEAN && G == 1 && P->chain.on;
+	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( chain_on ? 1 : 0 );
 	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
+	// the chain's working vectors -- where each base stands (5), two groups' vectors, a stem-loop's cores --
+	// take the place of the search records, which are not in use before pass B
+	unsigned long long	*const tv = reinterpret_cast<unsigned long long *>( lean_lo );
+	const bool	chain_vecs = chain_on && size_t( P->n_searches ) * BLOCK * LEAN_REC_BYTES >= size_t( 8 ) * pb_words * sizeof( unsigned long long );
 	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
 	// (the general instance's records take the same place; behind them the resume states of the
 	// levels up to the split level and the queue of continuations)
@@ -551,9 +557,16 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			t_ph = now_; \
 		} }while( 0 )
 	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
+	// (the ticket of the tile after this one is asked for while this one is worked on: the one counter all
+	// workgroups share answers in microseconds, and nobody should wait for it with a tile in hand)
+	long long	t_next = 0;
+	if( tid == 0 )
+		t_next = ( long long )atomicAdd( hb.ticket, 1ull );
 	for( ; ; ){
 		if( tid == 0 ){
-			const long long	t = ( long long )atomicAdd( hb.ticket, 1ull );
+			const long long	t = t_next;
+			if( t < n_units )
+				t_next = ( long long )atomicAdd( hb.ticket, 1ull );
 			const int	s = G == 1 && t < db.n_tiles ? db.tile_seq[ t ] : 0;
 			s_tile = t;
 			s_seq = s;
@@ -723,6 +736,15 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						if( lane_id == b5 )
 							rows[ b5 * pb_words + ( base >> 6 ) ] = m;
 					}
+					if( chain_vecs && rs == 0 ){
+						// where each base stands (the look-ahead pairs a position with another one: rmd_chain_t)
+						unsigned long long	*const isb = tv;
+						for( int b5 = 0; b5 < 5; b5++ ){
+							const unsigned long long	m = __ballot( code == b5 );
+							if( lane_id == b5 )
+								isb[ b5 * pb_words + ( base >> 6 ) ] = m;
+						}
+					}
 				}
 			}
 			SLOT_SYNC();
@@ -817,6 +839,80 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 				SLOT_SYNC();
 			}
+		}
+		// Look-ahead chain of the first element's interior (rmd_chain_t): start positions at which the
+		// interior's stem-loops cannot all be there are not searched.  tv[ 0 .. 4 ]: where each base stands;
+		// tv[ 5 ], tv[ 6 ]: a group's vector and the next group's, in turns; tv[ 7 ]: a stem-loop's cores;
+		// xv[ 0 ]: the start positions that remain.
+		const bool	chain = chain_vecs && bitpar && !( dbg & 32768 );
+		if( chain ){
+			const rmd_chain_t	&C = P->chain;
+			const int	vec_bits = vec_words * 64;
+			const unsigned	mat2 = rmd_pairsets( P )[ P->rowset_ps[ 0 ] ].mat2;
+			const int	nb = ( ( mat2 >> 20 ) & 31u ) || ( mat2 & 0x0108421u << 4 ) ? 5 : 4;		// (n pairs with nothing in the usual tables)
+			// 64 bits of a vector from bit x on; outside it: undecided, kept
+			auto	peek = [ & ]( const unsigned long long *v, int x ) -> unsigned long long {
+				return x >= 0 && x + 96 <= vec_bits ? bits64( v, x ) : ~0ull;
+			};
+			// the bases at x .. x+63 pair with the ones d further on
+			auto	pairs = [ & ]( int x, int d ) -> unsigned long long {
+				unsigned long long	m = 0;
+				for( int b = 0; b < nb; b++ )
+					m |= peek( tv + b * pb_words, x ) & peek( pb + b * pb_words, x + d );
+				return m;
+			};
+			int	cur = 0, core_key = -1;		// (stem-loops of one shape -- trna.descr's anticodon and T arms -- share their cores)
+			for( int k = C.n - 1; k >= 0; k-- ){
+				const rmd_chain_sib_t	sb = C.sib[ k ];
+				unsigned long long	*const dst = tv + ( 5 + cur ) * pb_words, *const core = tv + 7 * pb_words;
+				const unsigned long long	*const nxt = tv + ( 5 + ( cur ^ 1 ) ) * pb_words;
+				const int	key = ( int( sb.hmin ) << 20 ) | ( int( sb.lmin ) << 10 ) | int( sb.lmax );
+				if( sb.leaf && key != core_key ){
+					core_key = key;
+					// the innermost hmin pairs of the stem-loop, for one of its loop lengths
+					for( int wi = tid; wi < vec_words; wi += BLOCK ){
+						const int	x = wi * 64;
+						unsigned long long	f = 0;
+						for( int L = sb.lmin; L <= sb.lmax && ~f; L++ ){
+							unsigned long long	w1 = ~0ull;
+							for( int j = 0; j < sb.hmin && w1; j++ )
+								w1 &= pairs( x + j, 2 * sb.hmin + L - 1 - 2 * j );
+							f |= w1;
+						}
+						core[ wi ] = f;
+					}
+					__syncthreads();
+				}
+				for( int wi = tid; wi < vec_words; wi += BLOCK ){
+					const int	x = wi * 64;
+					unsigned long long	f = ~0ull;
+					if( sb.leaf ){
+						// ... which lie as far in as its helix is longer than the shortest
+						f = 0;
+						for( int t = 0; t <= sb.tmax && ~f; t++ )
+							f |= peek( core, x + t );
+					}
+					if( k < C.n - 1 && f ){
+						// ... and the next group one of this group's lengths later
+						unsigned long long	r = 0;
+						for( int len = sb.len_lo; len <= sb.len_hi && ~r; len++ )
+							r |= peek( nxt, x + len );
+						f &= r;
+					}
+					dst[ wi ] = f;
+				}
+				__syncthreads();
+				cur ^= 1;
+			}
+			const unsigned long long	*const g1 = tv + ( 5 + ( cur ^ 1 ) ) * pb_words;
+			for( int wi = tid; wi < vec_words; wi += BLOCK ){
+				const int	x = wi * 64;
+				unsigned long long	r = 0;
+				for( int h = C.s_lo; h <= C.s_hi && ~r; h++ )
+					r |= peek( g1, x + h );
+				xv[ wi ] = r;
+			}
+			__syncthreads();
 		}
 		if( bitpar ){
 			const int	hl0 = e0.minlen;
@@ -955,38 +1051,76 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					continue;
 				}
 				}
-				const int	rel = rel0;
-				const int	szero = z0 + rel;
-				bool	valid = valid0;
-				if( q1f && valid ){
-					// no place within reach for the 4-plex' second strand: nothing starts here
-					const int	bq = szero - p_lo + 64;
-					valid = ( xv[ 2 * pb_words + ( bq >> 6 ) ] >> ( bq & 63 ) ) & 1;
-				}
-				int	hi = 0, lo = 1;
-				if( valid )
-					rmd_level0_range( P, szero, slen, &hi, &lo );
-				for( int r0 = 0; r0 < n_rank; r0 += 64 ){
-					unsigned long long	W = 0;
-					if( valid && r0 <= hi - lo ){
-						W = win( szero, hi, r0, lo );
-						if( q1f && W ){
-							// ... and end positions before which no third strand can stand (bit i: end hi - r0 - 63 + i)
-							const int	bq = hi - r0 - 63 - p_lo + 64;
-							if( bq >= 0 && bq + 96 <= vec_words * 64 )
-								W &= bits64( xv + 3 * pb_words, bq );
+				// one start position per lane: the end positions that pass the first-pairs test are queued
+				auto	body = [ & ]( const int rel, const bool valid_in ){
+					const int	szero = z0 + rel;
+					bool	valid = valid_in;
+					if( q1f && valid ){
+						// no place within reach for the 4-plex' second strand: nothing starts here
+						const int	bq = szero - p_lo + 64;
+						valid = ( xv[ 2 * pb_words + ( bq >> 6 ) ] >> ( bq & 63 ) ) & 1;
+					}
+					int	hi = 0, lo = 1;
+					if( valid )
+						rmd_level0_range( P, szero, slen, &hi, &lo );
+					for( int r0 = 0; r0 < n_rank; r0 += 64 ){
+						unsigned long long	W = 0;
+						if( valid && r0 <= hi - lo ){
+							W = win( szero, hi, r0, lo );
+							if( q1f && W ){
+								// ... and end positions before which no third strand can stand (bit i: end hi - r0 - 63 + i)
+								const int	bq = hi - r0 - 63 - p_lo + 64;
+								if( bq >= 0 && bq + 96 <= vec_words * 64 )
+									W &= bits64( xv + 3 * pb_words, bq );
+							}
+						}
+						while( __ballot( W != 0 ) ){
+							const bool	has = W != 0;
+							const int	i = has ? __ffsll( W ) - 1 : 0;
+							const int	r = r0 + 63 - i;
+							// (the pinned tail helix of the interior, rmd_tail_ok(), is left to pass B:
+							// tested here it costs more in this divergent loop than it saves there)
+							QPUSH( has, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+							W &= W - 1;
 						}
 					}
-					while( __ballot( W != 0 ) ){
-						const bool	has = W != 0;
-						const int	i = has ? __ffsll( W ) - 1 : 0;
-						const int	r = r0 + 63 - i;
-						// (the pinned tail helix of the interior, rmd_tail_ok(), is left to pass B:
-						// tested here it costs more in this divergent loop than it saves there)
-						QPUSH( has, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
-						W &= W - 1;
+				};
+				if constexpr( LEAN && G == 1 ){
+				if( chain ){
+					// The look-ahead leaves a start position in twenty (trna.descr): collected per wave and
+					// taken 64 at a time, so that the row windows run with their lanes full.
+					__shared__ uint16_t	s_cbuf2[ BLOCK / 64 ][ 128 ];
+					uint16_t	*const cbuf = s_cbuf2[ tid >> 6 ];
+					if( valid0 ){
+						const int	bq = z0 + rel0 - p_lo + 64;
+						valid0 = ( xv[ bq >> 6 ] >> ( bq & 63 ) ) & 1;
 					}
+					const unsigned long long	mv = __ballot( valid0 );
+					if( valid0 )
+						cbuf[ n_wait + __popcll( mv & lt_mask ) ] = uint16_t( rel0 );
+					n_wait += __popcll( mv );
+					const bool	last_j = j + UNIT >= n_pos;
+					while( n_wait >= 64 || ( last_j && n_wait > 0 ) ){
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+						__builtin_amdgcn_wave_barrier();
+						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+						const int	n_take = n_wait < 64 ? n_wait : 64;
+						const bool	have = lane_id < n_take;
+						const int	rel = have ? int( cbuf[ lane_id ] ) : 0;
+						const int	rest = n_wait - n_take;
+						const int	moved = lane_id < rest ? int( cbuf[ n_take + lane_id ] ) : 0;
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+						__builtin_amdgcn_wave_barrier();
+						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+						if( lane_id < rest )
+							cbuf[ lane_id ] = uint16_t( moved );
+						n_wait = rest;
+						body( rel, have );
+					}
+					continue;
 				}
+				}
+				body( rel0, valid0 );
 			}
 		}else
 		for( int j = 0; j < n_pos; j += UNIT ){

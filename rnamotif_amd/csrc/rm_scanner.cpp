@@ -312,7 +312,10 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 {
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
 	// (bit vectors of a tile: the literal's, five per pair-row set, four of a leading 4-plex' strand filter, five more when a triplex follows it)
-	const size_t	pb_bytes = ( lean ? 6 : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? ( dp.q1f.t_on ? 9 : 4 ) : 0 ) ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	// (lean with a look-ahead chain: one more -- the start positions that remain; the chain's other vectors
+	// borrow the place of the search records, which pass A does not use)
+	const size_t	pb_bytes = ( lean ? 6 + ( dp.chain.on && group == 1 ? 1 : 0 ) : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? ( dp.q1f.t_on ? 9 : 4 ) : 0 ) ) *
+		( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;
@@ -435,7 +438,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 			}
 			density *= std::min( 1.0, pl * ( dp.lit_hi - dp.lit_lo + 1 ) );
 		}
-		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64;	// (static __shared__: 32 bytes)
+		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 1152;	// (static __shared__: the waves' buffers of start positions that passed the look-ahead, 1 KB, and 40 bytes)
 		// What the LDS queue cannot hold spills to HBM at 4 bytes per item, so LDS goes to the tile
 		// first and the queue gets what is left, up to the expected number of items (trna.descr:
 		// queue 1024 / T 9984 3.99 ms, 512 / 11008 3.94, 256 / 11520 3.91 -- the last spills a
@@ -1039,7 +1042,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	bool	pooled = false;
 	if( f.lean && !f.grouped ){
 		const int	n_dw = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;
-		const size_t	room = size_t( ( f.tile_bytes + 15 ) & ~15 ) + size_t( 6 ) * ( ( f.tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+		const size_t	room = size_t( ( f.tile_bytes + 15 ) & ~15 ) + size_t( 6 + ( dp.chain.on ? 1 : 0 ) ) * ( ( f.tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 		pooled = n_dw <= 32 && size_t( n_dw ) * SEARCH_BLOCK * sizeof( uint32_t ) <= room;
 		if( sc->opt.pool >= 0 )		// 0: pass B tile by tile (tests, profiles/pool_matrix.py)
 			pooled = pooled && sc->opt.pool != 0;
