@@ -491,7 +491,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// instance keeps one set, the first element's; the general one a set per pair table its helices use)
 	const int	n_rs = LEAN ? 1 : P->n_rowsets;
 	// (a 4-plex at the head of the search list: four more, rmd_q1filter_t)
-	const bool	q1f = !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on && !( dbg & 8192 );
+	const bool	q1f_vecs = !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on;
+	const bool	q1f = q1f_vecs && !( dbg & 8192 );
 	// (lean, one tile per pass, with a look-ahead chain: eight more, rmd_chain_t)
 	const bool	chain_on = LEAN && G == 1 && P->chain.on;
 	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( chain_on ? 1 : 0 );
@@ -619,32 +620,105 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			p_to = slen;
 		if( !live )
 			p_to = p_from;		// slot past the last tile: nothing to decode, no start position
-		// one packed word (16 bases) per lane and step; the reverse strand is the same words
-		// read backwards and complemented (mk_rcmp, rnamot.c:193)
-		if( p_from < p_to ){
-			const int	f_lo = comp ? slen - p_to : p_from, f_hi = comp ? slen - 1 - p_from : p_to - 1;
-			const int64_t	w_lo = ( off + f_lo ) >> 4, w_hi = ( off + f_hi ) >> 4;
-			for( int64_t wi = w_lo + utid; wi <= w_hi; wi += UNIT ){
-				const uint32_t	cw = db.codes[ wi ];
-				const uint32_t	am = db.amask[ wi >> 1 ] >> ( ( wi & 1 ) * 16 );
-				const int	f0 = int( ( wi << 4 ) - off );
-				for( int k = 0; k < 16; k++ ){
-					const int	f = f0 + k;
-					if( f < f_lo || f > f_hi )
-						continue;
-					int	c = ( am >> k ) & 1 ? RMA_BC_N : int( ( cw >> ( 2 * k ) ) & 3 );
-					if( comp && c < 4 )
-						c = 3 - c;
-					tile[ ( comp ? slen - 1 - f : f ) - p_lo ] = uint8_t( c );
+		// Tile position 0 is moved back (by less than 32) to where a group of 32 bases of the packed database
+		// begins -- counted from the entry's start for strand 0, from its end for strand 1, the same words
+		// read backwards and complemented (mk_rcmp, rnamot.c:193) -- so that one lane turns one such group
+		// into 32 positions of everything the tile holds: the byte per base, the bit vectors of where each
+		// base stands and, ORed from those by the pair table, the pair rows.  (Until round 3 a lane unpacked 16
+		// bases byte by byte and the rows were made by ten wave ballots per 64 positions: 0.78 of trna.descr's
+		// 2.4 ms.)
+		p_lo -= comp ? ( ( ( p_lo - slen ) % 32 ) + 32 ) % 32 : ( ( p_lo % 32 ) + 32 ) % 32;
+		vec_words = rmd_imin( pb_words, ( p_to - p_lo + 64 + 63 ) / 64 + 1 );	// bit vector words in use
+		{
+			const int	n_dw = ( p_to - p_lo + 31 ) / 32;
+			uint32_t	*const tile32 = reinterpret_cast<uint32_t *>( tile );
+			auto	even16 = []( uint32_t x ) -> uint32_t {		// bits 0, 2, 4 ... of x side by side
+				x &= 0x55555555u;
+				x = ( x | ( x >> 1 ) ) & 0x33333333u;
+				x = ( x | ( x >> 2 ) ) & 0x0f0f0f0fu;
+				x = ( x | ( x >> 4 ) ) & 0x00ff00ffu;
+				return ( x | ( x >> 8 ) ) & 0x0000ffffu;
+			};
+			auto	spread4 = []( uint32_t x ) -> uint32_t {	// bits 0 .. 3 of x to the low bits of four bytes
+				return __umul24( x & 15u, 0x00204081u ) & 0x01010101u;
+			};
+			for( int dd = utid; dd < vec_words * 2; dd += UNIT ){
+				const int	d = dd - 2;		// (64 pad bits in front of every vector)
+				uint32_t	b0 = 0, b1 = 0, nn = 0, valid = 0;
+				if( d >= 0 && d < n_dw ){
+					const int	q0 = 32 * d;
+					const int	fa = comp ? slen - 1 - ( p_lo + q0 ) : p_lo + q0;	// forward position of tile position q0
+					const int	f0 = comp ? fa - 31 : fa;				// ... of the group's first base
+					if( f0 >= 0 && f0 < slen ){
+						const int64_t	g = ( off + f0 ) >> 5;
+						const uint32_t	cw0 = db.codes[ 2 * g ], cw1 = db.codes[ 2 * g + 1 ];
+						nn = db.amask[ g ];
+						b0 = even16( cw0 ) | ( even16( cw1 ) << 16 );
+						b1 = even16( cw0 >> 1 ) | ( even16( cw1 >> 1 ) << 16 );
+						if( comp ){
+							b0 = ~__brev( b0 );
+							b1 = ~__brev( b1 );
+							nn = __brev( nn );
+						}
+					}
+					const int	v_lo = rmd_imax( 0, p_from - ( p_lo + q0 ) ), v_hi = rmd_imin( 32, p_to - ( p_lo + q0 ) );
+					if( v_hi > v_lo )
+						valid = ( v_hi - v_lo >= 32 ? ~0u : ( ( 1u << ( v_hi - v_lo ) ) - 1u ) ) << v_lo;
+					// the byte per base: 0 .. 3, 4 for a letter that is not acgt, 7 outside the entry
+					for( int k = 0; k < 8; k++ ){
+						const uint32_t	s0 = spread4( b0 >> ( 4 * k ) ), s1 = spread4( b1 >> ( 4 * k ) );
+						const uint32_t	sn = spread4( nn >> ( 4 * k ) ), sv = spread4( valid >> ( 4 * k ) );
+						uint32_t	by = ( ( s0 | ( s1 << 1 ) ) & ~( sn * 3u ) ) | ( sn << 2 );
+						by = ( by & ( sv * 7u ) ) | ( ( sv ^ 0x01010101u ) * 7u );
+						tile32[ 8 * d + k ] = by;
+					}
+				}
+				// where each base stands
+				const uint32_t	acgt = valid & ~nn;
+				const uint32_t	is[ 5 ] = { acgt & ~b1 & ~b0, acgt & ~b1 & b0, acgt & b1 & ~b0, acgt & b1 & b0, valid & nn };
+				// pair rows: rows[ b ] has a bit per tile position that can pair with 5' base b -- for the
+				// pre-filter's windows and for the helices of the search itself (RowEnds)
+				if( LEAN ? bitpar : n_rs > 0 )
+					for( int rs = 0; rs < n_rs; rs++ ){
+						const unsigned	mat2 = rmd_pairsets( P )[ P->rowset_ps[ rs ] ].mat2;
+						uint32_t	*const rows = reinterpret_cast<uint32_t *>( pb + 5 * rs * pb_words );
+						for( int b5 = 0; b5 < 5; b5++ ){
+							uint32_t	m = 0;
+							for( int c = 0; c < 5; c++ )
+								m |= is[ c ] & ( 0u - ( ( mat2 >> ( b5 * 5 + c ) ) & 1u ) );
+							rows[ b5 * pb_words * 2 + dd ] = m;
+						}
+					}
+				if( chain_vecs )
+					for( int b5 = 0; b5 < 5; b5++ )
+						reinterpret_cast<uint32_t *>( tv + b5 * pb_words )[ dd ] = is[ b5 ];
+				if( q1f_vecs ){
+					// strand filter of a leading 4-plex (rmd_q1filter_t): where a base stands that some quad has in
+					// second / third place, and the same for the triples of a triplex that follows
+					const rmd_q1filter_t	&F = P->q1f;
+					uint32_t	*const x32 = reinterpret_cast<uint32_t *>( pb + 5 * n_rs * pb_words );
+					auto	any_of = [ & ]( int mask ) -> uint32_t {
+						uint32_t	m = 0;
+						for( int c = 0; c < 5; c++ )
+							m |= is[ c ] & ( 0u - ( ( unsigned( mask ) >> c ) & 1u ) );
+						return m;
+					};
+					x32[ dd ] = any_of( F.m2 );
+					x32[ pb_words * 2 + dd ] = any_of( F.m3 );
+					if( F.t_on ){
+						x32[ 4 * pb_words * 2 + dd ] = any_of( F.tm1 );
+						x32[ 5 * pb_words * 2 + dd ] = any_of( F.tm2 );
+						x32[ 6 * pb_words * 2 + dd ] = any_of( F.tm3 );
+					}
 				}
 			}
 		}
 		SLOT_SYNC();
 		PHASE( 0 );
+		PHASE( 2 );
 		// short entries fill only part of a tile: the loops below run over what is there
 		const int	pos_end = rmd_imin( slen - P->dminlen + 1, pos_hi );
 		const int	n_pos = live ? rmd_imin( T, pos_end - z0 ) : 0;		// start positions of this tile
-		vec_words = rmd_imin( pb_words, ( p_to - p_lo + 64 + 63 ) / 64 + 1 );	// bit vector words in use
 		if constexpr( G > 1 ){
 			if( utid == 0 ){
 				int	*c = s_ctx[ slot ];
@@ -719,36 +793,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			} \
 		} }while( 0 )
 
-		// Pair rows: for every row set, rows[ b ] has a bit per tile position that can pair with 5'
-		// base b (one ballot per 64 positions and row), so "the first minlen pairs of (start, end)
-		// hold" is an AND of minlen shifted 64-bit windows, 64 end positions at a time -- for the
-		// pre-filter below and for the helices of the search itself (RowEnds).
-		if( LEAN ? bitpar : n_rs > 0 ){
-			const int	n_valid = p_to - p_lo;
-			for( int rs = 0; rs < n_rs; rs++ ){
-				const unsigned	mat2 = rmd_pairsets( P )[ P->rowset_ps[ rs ] ].mat2;
-				unsigned long long	*const rows = pb + 5 * rs * pb_words;
-				for( int base = ubase; base < vec_words * 64; base += UNIT ){
-					const int	q = base + lane_id - 64;		// one pad word in front
-					const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
-					for( int b5 = 0; b5 < 5; b5++ ){
-						const unsigned long long	m = __ballot( code < 5 && ( ( mat2 >> ( b5 * 5 + code ) ) & 1 ) );
-						if( lane_id == b5 )
-							rows[ b5 * pb_words + ( base >> 6 ) ] = m;
-					}
-					if( chain_vecs && rs == 0 ){
-						// where each base stands (the look-ahead pairs a position with another one: rmd_chain_t)
-						unsigned long long	*const isb = tv;
-						for( int b5 = 0; b5 < 5; b5++ ){
-							const unsigned long long	m = __ballot( code == b5 );
-							if( lane_id == b5 )
-								isb[ b5 * pb_words + ( base >> 6 ) ] = m;
-						}
-					}
-				}
-			}
-			SLOT_SYNC();
-			PHASE( 2 );
+		if constexpr( G == 1 ){
+			if( dbg & 65536 )		// (ablation: the tile is decoded and its rows are built; nothing is queued)
+				continue;
 		}
 		// Strand filter of a leading 4-plex (rmd_q1filter_t): G2 / G3 -- where a base stands that some quad
 		// has in second / third place -- then A -- start positions from which a second strand can be reached --
@@ -758,27 +805,6 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			const rmd_q1filter_t	F = P->q1f;
 			const bool	tri = F.t_on && !( dbg & 16384 );
 			const int	n_valid = p_to - p_lo, vec_bits = vec_words * 64;
-			for( int base = ubase; base < vec_words * 64; base += UNIT ){
-				const int	q = base + lane_id - 64;
-				const int	code = ( q >= p_from - p_lo && q < n_valid ) ? tile[ q ] : 7;
-				const unsigned long long	g2 = __ballot( code < 5 && ( ( F.m2 >> code ) & 1 ) );
-				const unsigned long long	g3 = __ballot( code < 5 && ( ( F.m3 >> code ) & 1 ) );
-				if( lane_id == 0 ){
-					xv[ base >> 6 ] = g2;
-					xv[ pb_words + ( base >> 6 ) ] = g3;
-				}
-				if( tri ){
-					const unsigned long long	t1 = __ballot( code < 5 && ( ( F.tm1 >> code ) & 1 ) );
-					const unsigned long long	t2 = __ballot( code < 5 && ( ( F.tm2 >> code ) & 1 ) );
-					const unsigned long long	t3 = __ballot( code < 5 && ( ( F.tm3 >> code ) & 1 ) );
-					if( lane_id == 0 ){
-						xv[ 4 * pb_words + ( base >> 6 ) ] = t1;
-						xv[ 5 * pb_words + ( base >> 6 ) ] = t2;
-						xv[ 6 * pb_words + ( base >> 6 ) ] = t3;
-					}
-				}
-			}
-			SLOT_SYNC();
 			// 64 positions from bit x on: can a strand stand there?  dir +1: read from its start onwards;
 			// -1: from its end backwards.  Bits the vectors do not hold: undecided, kept.
 			auto	stand = [ & ]( const unsigned long long *gv, int x, int dir, int nmin, int badmax, bool first5 ) -> unsigned long long {
@@ -913,6 +939,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				xv[ wi ] = r;
 			}
 			__syncthreads();
+		}
+		if constexpr( G == 1 ){
+			if( dbg & 131072 )		// (ablation: ... and the look-ahead chain; nothing is queued)
+				continue;
 		}
 		if( bitpar ){
 			const int	hl0 = e0.minlen;

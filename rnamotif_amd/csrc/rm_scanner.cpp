@@ -310,7 +310,7 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 // LDS of one search workgroup: program image | queue | tile | 6 bit vectors | lean records
 static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1 )
 {
-	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
+	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 80;
 	// (bit vectors of a tile: the literal's, five per pair-row set, four of a leading 4-plex' strand filter, five more when a triplex follows it)
 	// (lean with a look-ahead chain: one more -- the start positions that remain; the chain's other vectors
 	// borrow the place of the search records, which pass A does not use)
@@ -1031,7 +1031,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	const rmd_program_t	&dp = sc->dprog;
 	f.lean = dp.lean_ok && !( sc->opt.dbg & 16 );
 	f.grouped = f.lean && lay->group > 1;
-	f.tile_bytes = lay->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 16;
+	f.tile_bytes = lay->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 80;
 	f.lds = search_lds_bytes( sc->prog_bytes, dp, lay->tile_t, f.lean, lay->qcap, f.grouped ? SHORT_GROUP : 1 );
 	if( f.lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, f.lds );
