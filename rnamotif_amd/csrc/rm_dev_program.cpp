@@ -562,10 +562,12 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			ch.s_lo = int16_t( e0.minlen );
 			ch.s_hi = int16_t( e0.maxlen );
 			bool	any_leaf = false;
+			int	level_of[ RMD_MAX_CHAIN ];
 			for( int s = e0.inner_s; s >= 0 && ch.n < RMD_MAX_CHAIN; s = out->elems[ p->searches[ s ] ].next_s ){
 				const rmd_elem_t	&g = out->elems[ p->searches[ s ] ];
 				if( g.maxglen == RMA_UNBOUNDED || g.maxglen >= 2000 )
 					break;		// (what lies behind a group of any length is not pinned down by the start)
+				level_of[ ch.n ] = s;
 				rmd_chain_sib_t	&sb = ch.sib[ ch.n++ ];
 				sb.len_lo = int16_t( g.minglen );
 				sb.len_hi = int16_t( g.maxglen );
@@ -600,6 +602,48 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			// (drop groups behind the last stem-loop: they say nothing)
 			while( ch.n > 0 && !ch.sib[ ch.n - 1 ].leaf )
 				ch.n--;
+			// the cores of the first two shapes of stem-loop are kept for the candidate test of pass A'
+			{
+				int	keys[ 2 ] = { -1, -1 };
+				for( int k = ch.n - 1; k >= 0; k-- ){		// (the order the kernel computes them in)
+					rmd_chain_sib_t	&sb = ch.sib[ k ];
+					sb.core_slot = -1;
+					if( !sb.leaf )
+						continue;
+					const int	key = ( int( sb.hmin ) << 20 ) | ( int( sb.lmin ) << 10 ) | int( sb.lmax );
+					for( int q = 0; q < 2; q++ )
+						if( keys[ q ] == key || keys[ q ] < 0 ){
+							keys[ q ] = key;
+							sb.core_slot = int8_t( q );
+							break;
+						}
+				}
+			}
+			// the first helix of the interior and the stem-loop that follows it behind single strands only
+			if( e0.head_s >= 0 )
+				for( int k = 0; k < ch.n; k++ ){
+					if( level_of[ k ] != e0.head_s )
+						continue;
+					long	glo = 0, ghi = 0;
+					for( int j = k + 1; j < ch.n; j++ ){
+						const rmd_chain_sib_t	&sj = ch.sib[ j ];
+						if( sj.leaf ){
+							if( sj.core_slot >= 0 && ghi - glo < 24 && ghi < 1000 ){
+								ch.hn_on = 1;
+								ch.hn_slot = sj.core_slot;
+								ch.hn_tmax = sj.tmax;
+								ch.hn_glo = int16_t( glo );
+								ch.hn_ghi = int16_t( ghi );
+							}
+							break;
+						}
+						if( out->elems[ p->searches[ level_of[ j ] ] ].type != RMA_T_SS )
+							break;
+						glo += sj.len_lo;
+						ghi += sj.len_hi;
+					}
+					break;
+				}
 			ch.on = any_leaf && ch.n > 0;
 		}
 	}

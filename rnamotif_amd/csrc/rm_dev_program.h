@@ -146,9 +146,18 @@ struct rmd_chain_sib_t {
 	int16_t	tmax;			// leaf: longest minus shortest helix (the core of hmin pairs lies 0 .. tmax in)
 	int16_t	lmin, lmax;		// leaf: loop lengths
 	int16_t	len_lo, len_hi;		// total length of the group
+	int8_t	core_slot;		// leaf: which of the two kept core vectors is its own (-1: none kept)
+	int8_t	pad_;
 };
 struct rmd_chain_t {
 	int8_t	on, n;
+	// The candidate test of pass A' (pooled instance) knows the 3' ends at which the first helix of the
+	// interior (rmd_elem_t::head_s) can close; when only single strands of hn_glo .. hn_ghi bases lie between
+	// it and the next stem-loop, one of those ends must have that stem-loop's core hn_glo + 1 .. hn_ghi + 1 +
+	// hn_tmax behind it (trna.descr: a D arm that closes two bases before an anticodon arm -- one
+	// candidate in twenty).  hn_on = 0: no such pair of neighbours.
+	int8_t	hn_on, hn_slot;
+	int16_t	hn_tmax, hn_glo, hn_ghi;
 	int16_t	s_lo, s_hi;		// first group starts s_lo .. s_hi after the start position (the outer helix' lengths)
 	rmd_chain_sib_t	sib[ RMD_MAX_CHAIN ];
 };

@@ -22,7 +22,7 @@ struct DevHitSort {
 	int	*d_flag = nullptr;
 	int64_t	cap = 0;
 	int	stride = 0;
-	int	w_ord = 8;	// bits for the order word; widened after a scan whose order words did not fit
+	int	w_ord = 20;	// bits for the order word (pieces of items count in their own ranges, rm_scan_kernel.h PIECE_ORDER_BITS); widened after a scan whose order words did not fit
 
 	// room for cap records of stride words
 	hipError_t	reserve( int64_t cap, int stride );

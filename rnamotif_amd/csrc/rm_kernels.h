@@ -27,9 +27,13 @@ struct HitBuf {
 	int64_t	cap;
 	unsigned	*spill;			// [gridDim.x][spill_cap] work queue items that did not fit the LDS queue
 	int	spill_cap;
-	unsigned	*pool;			// [gridDim.x][pool_cap][3] pooled instance: items that passed the tile's tests
+	unsigned	*pool;			// [glist_cap + gridDim.x * pool_cap][RMK_POOL_WORDS] pooled instance: items that passed the tile's tests
 	int	pool_cap, pool_min;	// ... searched once pool_min of them have come together
 	int	pool_refill;		// idle lanes of a wave that pop together
+	// pooled instance with a drain kernel (glist_cap > 0): the device-wide list the workgroups' pools are flushed to
+	// is the first glist_cap items at `pool`, the workgroups' own areas come after it; ticket[ RMK_GCTL - 1 ] counts
+	// the items reserved in it (may exceed glist_cap), ticket[ RMK_GCTL ] those taken (rma_drain_kernel)
+	int	glist_cap;
 };
 
 // ---------------------------------------------------------------- launch-shape constants
@@ -60,6 +64,11 @@ struct HitBuf {
 #endif
 #define SHORT_ENTRY_MEAN	4000	// ... which are those whose entries average less than this
 #define SPILL_ITEMS		8192	// queue items per workgroup that may overflow into HBM (32 KB each, 64 MB in all)
+#define RMK_POOL_WORDS		5	// entry, start, rank | strand, and the 3' ends the first helix of the interior may take (two outer lengths)
+#define RMK_N_COUNTERS		128	// 64-bit counters behind a launch: [0] candidates, [1] ticket, diagnostics, [RMK_GCTL] the list's two
+#define RMK_GCTL		100
+#define PIECE_ORDER_BITS	12	// candidates a piece of an item may find; more, and the search is repeated with whole items (ticket[ 2 ])
+#define GLIST_FLUSH		32	// items a workgroup's pool holds when it is flushed to the list (and whatever it holds at the end)
 #define SEARCH_BLOCK		256	// lanes of a search workgroup of the lean instances
 // ... and of the general instances: ONE wave.  The waves of a four-wave workgroup met at the end of
 // every tile, and the tile's second round -- a few dozen continuations, each a long walk -- kept one of
@@ -96,6 +105,7 @@ struct rmk_search_args {
 hipError_t	rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 // the launchers behind it, one translation unit each (rm_scan_inst_*.hip)
 hipError_t	rmk_launch_lean_pool( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_lean_drain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );	// (qcap, tile_bytes: not used)
 hipError_t	rmk_launch_lean_group( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_tile( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_plain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );

@@ -53,6 +53,11 @@ struct rmd_lane_t {
 	int32_t	l_off, l_len, r_off, r_len, l_mm, r_mm;
 	int32_t	slen, szero;
 	int32_t	rank, order;
+	// (the end-of-list checks below read the table through these, so that a kernel can keep it
+	// spread over the lanes of a wave instead: rm_scan_kernel.h WaveTable)
+	RMD_FN_MEMBER int	off( int d ) const { return moff[ d ]; }
+	RMD_FN_MEMBER int	len( int d ) const { return mlen[ d ]; }
+	RMD_FN_MEMBER int	wtype( const rmd_program_t *P, int pos, int undef_is_ss ) const;
 };
 
 // sequence view: code of absolute position p is sq[ p - sq0 ]
@@ -438,17 +443,17 @@ RMD_FN int rmd_skip_unpaired_ends( const rmd_program_t *P, const rmd_elem_t &stp
 // ---------------------------------------------------------------- terminal checks
 // fm_window[] lookup (find_motif.c:1333-1385 marks): type of the element that
 // covers position pos, RMA_T_SS when nothing does and undef_is_ss, else -1.
-RMD_FN int rmd_wtype( const rmd_program_t *P, const rmd_lane_t *L, int pos, int undef_is_ss )
+RMD_FN_MEMBER int rmd_lane_t::wtype( const rmd_program_t *P, int pos, int undef_is_ss ) const
 {
 	for( int d = 0; d < P->n_elems; d++ ){
-		if( L->mlen[ d ] > 0 && pos >= L->moff[ d ] && pos < L->moff[ d ] + L->mlen[ d ] )
+		if( mlen[ d ] > 0 && pos >= moff[ d ] && pos < moff[ d ] + mlen[ d ] )
 			return P->elems[ d ].type;
 	}
 	return undef_is_ss ? RMA_T_SS : -1;
 }
 
-template< class SQ >
-RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const SQ &sq )	// chk_motif :1406
+template< class TB, class SQ >
+RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const TB &L, const SQ &sq )	// chk_motif :1406
 {
 	for( int d = 0; d < P->n_elems; d++ ){
 		const rmd_elem_t	&stp = P->elems[ d ];
@@ -456,51 +461,51 @@ RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const S
 			continue;
 		if( stp.type == RMA_T_H5 ){			// chk_wchlx :1441
 			int	d3 = stp.mates[ 0 ];
-			int	h5_5 = L->moff[ d ], h5_3 = h5_5 + L->mlen[ d ] - 1;
-			int	h3_5 = L->moff[ d3 ], h3_3 = h3_5 + L->mlen[ d3 ] - 1;
-			if( ( stp.strict & RMA_5STRICT ) && h5_5 > 0 && h3_3 < L->slen - 1 ){
-				if( rmd_wtype( P, L, h5_5 - 1, 1 ) == RMA_T_SS && rmd_wtype( P, L, h3_3 + 1, 1 ) == RMA_T_SS &&
+			int	h5_5 = L.off( d ), h5_3 = h5_5 + L.len( d ) - 1;
+			int	h3_5 = L.off( d3 ), h3_3 = h3_5 + L.len( d3 ) - 1;
+			if( ( stp.strict & RMA_5STRICT ) && h5_5 > 0 && h3_3 < L.slen - 1 ){
+				if( L.wtype( P, h5_5 - 1, 1 ) == RMA_T_SS && L.wtype( P, h3_3 + 1, 1 ) == RMA_T_SS &&
 					rmd_paired( P, stp.pairset, rmd_code( sq, h5_5 - 1 ), rmd_code( sq, h3_3 + 1 ) ) )
 					return 0;
 			}
 			if( stp.strict & RMA_3STRICT ){
-				if( rmd_wtype( P, L, h5_3 + 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, h3_5 - 1, 0 ) == RMA_T_SS &&
+				if( L.wtype( P, h5_3 + 1, 0 ) == RMA_T_SS && L.wtype( P, h3_5 - 1, 0 ) == RMA_T_SS &&
 					rmd_paired( P, stp.pairset, rmd_code( sq, h5_3 + 1 ), rmd_code( sq, h3_5 - 1 ) ) )
 					return 0;
 			}
 		}else if( stp.type == RMA_T_T1 ){		// chk_triplex :1557
 			int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ];
-			int	t1_5 = L->moff[ d ], t1_3 = t1_5 + L->mlen[ d ] - 1;
-			int	t2_5 = L->moff[ d1 ], t2_3 = t2_5 + L->mlen[ d1 ] - 1;
-			int	t3_5 = L->moff[ d2 ], t3_3 = t3_5 + L->mlen[ d2 ] - 1;
+			int	t1_5 = L.off( d ), t1_3 = t1_5 + L.len( d ) - 1;
+			int	t2_5 = L.off( d1 ), t2_3 = t2_5 + L.len( d1 ) - 1;
+			int	t3_5 = L.off( d2 ), t3_3 = t3_5 + L.len( d2 ) - 1;
 			if( ( stp.strict & RMA_5STRICT ) && t1_5 > 0 ){
-				if( rmd_wtype( P, L, t1_5 - 1, 1 ) == RMA_T_SS && rmd_wtype( P, L, t2_3 + 1, 0 ) == RMA_T_SS &&
-					rmd_wtype( P, L, t3_5 - 1, 0 ) == RMA_T_SS &&
+				if( L.wtype( P, t1_5 - 1, 1 ) == RMA_T_SS && L.wtype( P, t2_3 + 1, 0 ) == RMA_T_SS &&
+					L.wtype( P, t3_5 - 1, 0 ) == RMA_T_SS &&
 					rmd_triple( P, stp.pairset, rmd_code( sq, t1_5 - 1 ), rmd_code( sq, t2_3 + 1 ), rmd_code( sq, t3_5 - 1 ) ) )
 					return 0;
 			}
-			if( ( stp.strict & RMA_3STRICT ) && t3_3 < L->slen - 1 ){
-				if( rmd_wtype( P, L, t1_3 + 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, t2_5 - 1, 0 ) == RMA_T_SS &&
-					rmd_wtype( P, L, t3_3 + 1, 1 ) == RMA_T_SS &&
+			if( ( stp.strict & RMA_3STRICT ) && t3_3 < L.slen - 1 ){
+				if( L.wtype( P, t1_3 + 1, 0 ) == RMA_T_SS && L.wtype( P, t2_5 - 1, 0 ) == RMA_T_SS &&
+					L.wtype( P, t3_3 + 1, 1 ) == RMA_T_SS &&
 					rmd_triple( P, stp.pairset, rmd_code( sq, t1_3 + 1 ), rmd_code( sq, t2_5 - 1 ), rmd_code( sq, t3_3 + 1 ) ) )
 					return 0;
 			}
 		}else if( stp.type == RMA_T_Q1 ){		// chk_4plex :1629
 			int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
-			int	q1_5 = L->moff[ d ], q1_3 = q1_5 + L->mlen[ d ] - 1;
-			int	q2_5 = L->moff[ d1 ], q2_3 = q2_5 + L->mlen[ d1 ] - 1;
-			int	q3_5 = L->moff[ d2 ], q3_3 = q3_5 + L->mlen[ d2 ] - 1;
-			int	q4_5 = L->moff[ d3 ], q4_3 = q4_5 + L->mlen[ d3 ] - 1;
-			if( ( stp.strict & RMA_5STRICT ) && q1_5 > 0 && q4_3 < L->slen - 1 ){
-				if( rmd_wtype( P, L, q1_5 - 1, 1 ) == RMA_T_SS && rmd_wtype( P, L, q2_3 + 1, 0 ) == RMA_T_SS &&
-					rmd_wtype( P, L, q3_5 - 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, q4_3 + 1, 1 ) == RMA_T_SS &&
+			int	q1_5 = L.off( d ), q1_3 = q1_5 + L.len( d ) - 1;
+			int	q2_5 = L.off( d1 ), q2_3 = q2_5 + L.len( d1 ) - 1;
+			int	q3_5 = L.off( d2 ), q3_3 = q3_5 + L.len( d2 ) - 1;
+			int	q4_5 = L.off( d3 ), q4_3 = q4_5 + L.len( d3 ) - 1;
+			if( ( stp.strict & RMA_5STRICT ) && q1_5 > 0 && q4_3 < L.slen - 1 ){
+				if( L.wtype( P, q1_5 - 1, 1 ) == RMA_T_SS && L.wtype( P, q2_3 + 1, 0 ) == RMA_T_SS &&
+					L.wtype( P, q3_5 - 1, 0 ) == RMA_T_SS && L.wtype( P, q4_3 + 1, 1 ) == RMA_T_SS &&
 					rmd_quad( P, stp.pairset, rmd_code( sq, q1_5 - 1 ), rmd_code( sq, q2_3 + 1 ),
 						rmd_code( sq, q3_5 - 1 ), rmd_code( sq, q4_3 + 1 ) ) )
 					return 0;
 			}
 			if( stp.strict & RMA_3STRICT ){		// (sic) :1706 never looks at the q4 side
-				if( rmd_wtype( P, L, q1_3 + 1, 0 ) == RMA_T_SS && rmd_wtype( P, L, q2_5 - 1, 0 ) == RMA_T_SS &&
-					rmd_wtype( P, L, q3_3 + 1, 0 ) == RMA_T_SS &&
+				if( L.wtype( P, q1_3 + 1, 0 ) == RMA_T_SS && L.wtype( P, q2_5 - 1, 0 ) == RMA_T_SS &&
+					L.wtype( P, q3_3 + 1, 0 ) == RMA_T_SS &&
 					rmd_quad( P, stp.pairset, rmd_code( sq, q1_3 + 1 ), rmd_code( sq, q2_5 - 1 ),
 						rmd_code( sq, q3_3 + 1 ), rmd_code( sq, q4_5 - 1 ) ) )
 					return 0;
@@ -511,44 +516,44 @@ RMD_COLD int rmd_chk_motif( const rmd_program_t *P, const rmd_lane_t *L, const S
 	return 1;
 }
 
-template< class SQ >
-RMD_COLD int rmd_set_context( const rmd_program_t *P, rmd_lane_t *L, const SQ &sq )	// set_context :1720
+template< class TB, class SQ >
+RMD_COLD int rmd_set_context( const rmd_program_t *P, TB &L, const SQ &sq )	// set_context :1720
 {
 	if( P->has_lctx ){
-		int	off = L->moff[ 0 ] - P->lctx.maxlen;
+		int	off = L.off( 0 ) - P->lctx.maxlen;
 		if( off < 0 )
 			off = 0;
-		L->l_off = off;
-		L->l_len = L->moff[ 0 ] - off;
-		if( L->l_len < P->lctx.minlen )
+		L.l_off = off;
+		L.l_len = L.off( 0 ) - off;
+		if( L.l_len < P->lctx.minlen )
 			return 0;
-		if( P->lctx.re >= 0 && !rmd_chk_seq( P, P->lctx, sq, off, L->l_len, &L->l_mm ) )
+		if( P->lctx.re >= 0 && !rmd_chk_seq( P, P->lctx, sq, off, L.l_len, &L.l_mm ) )
 			return 0;
 	}
 	if( P->has_rctx ){
 		int	n = P->n_elems - 1;
-		L->r_off = L->moff[ n ] + L->mlen[ n ];
-		int	end = L->r_off + P->rctx.maxlen;
-		if( end > L->slen )
-			end = L->slen;
-		L->r_len = end - L->r_off;
-		if( L->r_len < P->rctx.minlen )
+		L.r_off = L.off( n ) + L.len( n );
+		int	end = L.r_off + P->rctx.maxlen;
+		if( end > L.slen )
+			end = L.slen;
+		L.r_len = end - L.r_off;
+		if( L.r_len < P->rctx.minlen )
 			return 0;
 		if( P->rctx.re >= 0 ){
 			// (sic) :1749-1751 matches from the END of the context; the C string
 			// it builds stops at the end of the sequence
-			int	len = L->r_len;
-			if( len > L->slen - end )
-				len = L->slen - end;
-			if( !rmd_chk_seq( P, P->rctx, sq, end, len, &L->r_mm ) )
+			int	len = L.r_len;
+			if( len > L.slen - end )
+				len = L.slen - end;
+			if( !rmd_chk_seq( P, P->rctx, sq, end, len, &L.r_mm ) )
 				return 0;
 		}
 	}
 	return 1;
 }
 
-template< class SQ >
-RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const SQ &sq )	// chk_sites :1758
+template< class TB, class SQ >
+RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const TB &L, const SQ &sq )	// chk_sites :1758
 {
 	for( int s = 0; s < P->n_sites; s++ ){
 		const rmd_site_t	&si = rmd_sites( P )[ s ];
@@ -556,13 +561,13 @@ RMD_COLD int rmd_chk_sites( const rmd_program_t *P, const rmd_lane_t *L, const S
 		for( int k = 0; k < si.n_pos; k++ ){
 			int	d = si.elem[ k ], pos;
 			if( si.l2r[ k ] ){
-				if( si.offset[ k ] > L->mlen[ d ] )
+				if( si.offset[ k ] > L.len( d ) )
 					return 0;
-				pos = L->moff[ d ] + si.offset[ k ] - 1;
-			}else if( si.offset[ k ] >= L->mlen[ d ] )
+				pos = L.off( d ) + si.offset[ k ] - 1;
+			}else if( si.offset[ k ] >= L.len( d ) )
 				return 0;
 			else
-				pos = L->moff[ d ] + L->mlen[ d ] - si.offset[ k ] - 1;
+				pos = L.off( d ) + L.len( d ) - si.offset[ k ] - 1;
 			b[ k ] = rmd_code( sq, pos );
 		}
 		int	rv = 0;
@@ -666,6 +671,19 @@ struct rmd_lean_t {
 	int32_t	hi0, lo0;	// first level: end position of rank 0, lowest end position allowed
 	int32_t	rank, order;
 	int32_t	pretested;	// the item is one end position that already passed the first-pairs test
+	// The 3' ends level hm_level (the first helix of the first element's interior) is allowed to take, as the
+	// caller's tests found them (the kernel's pass A', from pair rows and stem-loop cores: necessary
+	// conditions, so the ends left out lead to no candidate): bit j of hmask[ i ] = end number j, counted from
+	// the shortest the helix may have, when the first element has its i-th length.  hm_level < 0: none.
+	int32_t	hm_level;
+	uint32_t	hmask[ 2 ];
+	// >= 0: the walk takes this one length of the first element only (the caller walks the others as items of
+	// their own; the candidates' order words tell the pieces apart, see the kernel's drain)
+	int32_t	only_hl;
+	// rmd_lean_step< ..., DEFER = true >() does not run the end-of-list checks of a complete structural
+	// match itself (rmd_lean_emit): it sets this and returns, the caller runs them (the kernel does, all
+	// lanes of the wave on one match: wave_emit), clears it and counts `order` up if the candidate was stored.
+	int32_t	pending;
 };
 
 // The interior [a, b] (relative to z) of helix stp ends with a proper helix whose 3' strand
@@ -717,6 +735,9 @@ RMD_FN int rmd_lean_begin( const rmd_program_t *P, LR &lr, rmd_lean_t &st, int s
 	st.slen = slen;
 	st.rank = -1;
 	st.order = 0;
+	st.hm_level = -1;
+	st.only_hl = -1;
+	st.pending = 0;
 	int	d0 = rmd_imin( szero + P->w_winsize - 1, slen - 1 ) - szero;
 	rmd_lrec_t	r = rmd_lean_open( P, 0, 0, d0 );
 	const rmd_elem_t	&stp = P->elems[ P->searches[ 0 ] ];
@@ -772,11 +793,11 @@ RMD_FN void rmd_lean_emit( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const
 	L->order = st.order;
 	L->l_mm = L->r_mm = RMD_UNDEF;
 	L->l_off = L->l_len = L->r_off = L->r_len = 0;
-	if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
+	if( P->strict_helices && !rmd_chk_motif( P, *L, sq ) )
 		return;
-	if( !rmd_set_context( P, L, sq ) )
+	if( !rmd_set_context( P, *L, sq ) )
 		return;
-	if( !rmd_chk_sites( P, L, sq ) )
+	if( !rmd_chk_sites( P, *L, sq ) )
 		return;
 	sink.put( P, L, z );
 	st.order++;
@@ -789,7 +810,7 @@ struct rmd_no_accel_t {
 	RMD_FN_MEMBER bool	tail( const rmd_elem_t &, int, int, int, bool * ) const { return false; }
 };
 
-template< class LR, class Sink, class SQ, class Accel = rmd_no_accel_t >
+template< class LR, class Sink, class SQ, class Accel = rmd_no_accel_t, bool DEFER = false >
 RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const SQ &sq, int k,
 	rmd_lane_t *L, Sink &sink, const Accel &accel = Accel() )
 {
@@ -810,6 +831,8 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 			rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
 				rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 );
 			cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+			if( k == 0 && st.only_hl >= 0 )
+				cand &= 1ull << st.only_hl;
 		}
 	}
 	for( ; ; ){
@@ -832,6 +855,12 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 			if( r.sd < lo )
 				return k - 1;
 			cur = r.sd--;
+			if( k == st.hm_level ){
+				// an end the caller's tests have ruled out for this length of the first element
+				const int	i0 = int( lr.get( 0 ).hl ) - P->elems[ P->searches[ 0 ] ].minlen, j = cur - ( r.zero + stp.minglen - 1 );
+				if( i0 >= 0 && i0 < 2 && j >= 0 && j < 32 && !( ( st.hmask[ i0 ] >> j ) & 1u ) )
+					continue;
+			}
 			if( stp.loop ){
 				if( k == 0 ){
 					st.rank = st.hi0 - cur;
@@ -876,7 +905,10 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 				}
 				r.ph = 1;
 				lr.set( k, r );
-				rmd_lean_emit( P, lr, st, sq, L, sink );
+				if constexpr( DEFER )
+					st.pending = 1;
+				else
+					rmd_lean_emit( P, lr, st, sq, L, sink );
 				return k;
 			}
 			int	mm5 = 0, mm3 = 0;
@@ -884,6 +916,11 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 				rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 ) ){
 				cand = 0;
 				continue;
+			}
+			if( k == 0 && st.only_hl >= 0 ){
+				cand &= 1ull << st.only_hl;
+				if( cand == 0 )
+					continue;
 			}
 		}
 		// helix: next accepted length, find_wchlx :435-460
@@ -1676,11 +1713,11 @@ RMD_GEN_FN void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, con
 	L->order = st.tag >= 0 ? st.tag : st.order;
 	L->l_mm = L->r_mm = RMD_UNDEF;
 	L->l_off = L->l_len = L->r_off = L->r_len = 0;
-	if( P->strict_helices && !rmd_chk_motif( P, L, sq ) )
+	if( P->strict_helices && !rmd_chk_motif( P, *L, sq ) )
 		return;
-	if( !rmd_set_context( P, L, sq ) )
+	if( !rmd_set_context( P, *L, sq ) )
 		return;
-	if( !rmd_chk_sites( P, L, sq ) )
+	if( !rmd_chk_sites( P, *L, sq ) )
 		return;
 	sink.put( P, L, z );
 	if( st.tag < 0 )

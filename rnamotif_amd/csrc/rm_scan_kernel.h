@@ -87,6 +87,183 @@ struct LdsRecs {
 	}
 };
 
+// ---------------------------------------------------------------- a complete match, the whole wave on it
+// What rmd_lean_emit() does for one lane -- rebuild the element table from the search records, run the
+// end-of-list checks, store the candidate (find_ss :362-393) -- takes that lane some 150 000 cycles: the
+// table (s_matchoff ... of up to 100 elements, indexed at run time) lives in scratch memory, and
+// chk_motif's fm_window lookups walk it element by element, four times per strict helix; the other lanes
+// of the wave wait meanwhile, and an item with twenty alternatives holds its wave for milliseconds
+// (RNAMOTIF_DBG=34: 38 % of pass B's wave cycles over trna.descr, and all of its tail).  Here the
+// wave does it together: lane j rebuilds search levels j and j + 64 from the records of the lane that
+// found the match, lane e keeps elements e and e + 64 of the table in registers, a window lookup is a
+// ballot, the candidate's words go out side by side.  No scratch memory, a few thousand cycles.
+struct WaveTable {
+	int	moff[ 2 ], mlen[ 2 ], type[ 2 ], mpr[ 2 ], mm[ 2 ];	// of elements lane and lane + 64
+	int	l_off, l_len, r_off, r_len, l_mm, r_mm;		// (the same in every lane)
+	int	slen;
+	// (d is the same in every lane wherever the checks call these)
+	__device__ inline int	off( int d ) const
+	{
+		const int	a = __shfl( moff[ 0 ], d & 63 ), b = __shfl( moff[ 1 ], d & 63 );
+		return d < 64 ? a : b;
+	}
+	__device__ inline int	len( int d ) const
+	{
+		const int	a = __shfl( mlen[ 0 ], d & 63 ), b = __shfl( mlen[ 1 ], d & 63 );
+		return d < 64 ? a : b;
+	}
+	__device__ inline int	wtype( const rmd_program_t *, int pos, int undef_is_ss ) const	// rmd_lane_t::wtype: the first element that covers pos
+	{
+		const unsigned long long	b0 = __ballot( mlen[ 0 ] > 0 && pos >= moff[ 0 ] && pos < moff[ 0 ] + mlen[ 0 ] );
+		const unsigned long long	b1 = __ballot( mlen[ 1 ] > 0 && pos >= moff[ 1 ] && pos < moff[ 1 ] + mlen[ 1 ] );
+		const int	t0 = __shfl( type[ 0 ], b0 ? __ffsll( b0 ) - 1 : 0 ), t1 = __shfl( type[ 1 ], b1 ? __ffsll( b1 ) - 1 : 0 );
+		return b0 ? t0 : b1 ? t1 : undef_is_ss ? RMA_T_SS : -1;
+	}
+};
+
+// All 64 lanes call this with the same arguments: the records (lr), the sequence view and the search
+// state of the lane whose search reached the end of the list.  True when the candidate passed the checks
+// (and was stored, room permitting): the caller counts that lane's `order` up.
+template< int BLOCK, class LR, class SQ >
+__device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, const SQ sq, int z, int slen, int rank, int order,
+	int seq, int comp, int32_t *hits, unsigned long long *count, long long cap, int lane_id )
+{
+	// lane j: levels j and j + 64, as rmd_lean_emit's loop has them
+	int	lz[ 2 ] = { 0, 0 }, lc[ 2 ] = { 0, 0 }, lx[ 2 ] = { 0, 0 }, lm[ 2 ] = { 0, 0 };
+#pragma unroll
+	for( int s = 0; s < 2; s++ ){
+		const int	kk = lane_id + 64 * s;
+		if( kk < P->n_searches ){
+			const rmd_lrec_t	r = lr.get( kk );
+			const int	d = P->searches[ kk ];
+			const rmd_elem_t	&stp = P->elems[ d ];
+			const int	zero = z + r.zero, cur = z + r.sd + 1;
+			lz[ s ] = zero;
+			lc[ s ] = cur;
+			if( stp.type == RMA_T_SS ){
+				int	mm = 0;
+				if( stp.re >= 0 && stp.mismatch > 0 )
+					rmd_chk_seq( P, stp, sq, zero, cur - zero + 1, &mm );
+				lm[ s ] = mm & 0xffff;
+			}else{
+				const int	hl = r.hl;
+				uint64_t	cand, mis;
+				int	mm5 = 0, mm3 = 0;
+				rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], zero, cur, rmd_s3lim( zero, cur, stp.minilen, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
+				lx[ s ] = hl | ( rmd_popc64( mis & ( ( 1ull << hl ) - 1 ) ) << 8 );
+				lm[ s ] = ( mm5 & 0xffff ) | ( mm3 << 16 );
+			}
+		}
+	}
+	// lane e: elements e and e + 64, each from the level that placed it (a 3' strand: its helix's)
+	WaveTable	tb;
+#pragma unroll
+	for( int s = 0; s < 2; s++ ){
+		const int	e = lane_id + 64 * s;
+		const bool	in = e < P->n_elems;
+		const rmd_elem_t	&el = P->elems[ in ? e : 0 ];
+		const int	ty = el.type;
+		const int	lv_ = ty == RMA_T_H3 ? P->elems[ el.mates[ 0 ] ].searchno : el.searchno;
+		const bool	placed = in && lv_ >= 0;
+		const int	lv = placed ? lv_ : 0, src = lv & 63;
+		const int	z0 = __shfl( lz[ 0 ], src ), z1 = __shfl( lz[ 1 ], src ), c0 = __shfl( lc[ 0 ], src ), c1 = __shfl( lc[ 1 ], src );
+		const int	x0 = __shfl( lx[ 0 ], src ), x1 = __shfl( lx[ 1 ], src ), m0 = __shfl( lm[ 0 ], src ), m1 = __shfl( lm[ 1 ], src );
+		const int	zero = lv < 64 ? z0 : z1, cur = lv < 64 ? c0 : c1, x = lv < 64 ? x0 : x1, m = lv < 64 ? m0 : m1;
+		const int	hl = x & 0xff;
+		tb.type[ s ] = in ? ty : -1;
+		tb.moff[ s ] = !placed ? 0 : ty == RMA_T_H3 ? cur - hl + 1 : zero;
+		tb.mlen[ s ] = !placed ? 0 : ty == RMA_T_SS ? cur - zero + 1 : hl;
+		tb.mpr[ s ] = !placed || ty == RMA_T_SS ? 0 : x >> 8;
+		tb.mm[ s ] = !placed ? 0 : ty == RMA_T_H3 ? ( m >> 16 ) : int( int16_t( m & 0xffff ) );
+	}
+	tb.slen = slen;
+	tb.l_mm = tb.r_mm = RMD_UNDEF;
+	tb.l_off = tb.l_len = tb.r_off = tb.r_len = 0;
+	if( P->strict_helices && !rmd_chk_motif( P, tb, sq ) )
+		return false;
+	if( !rmd_set_context( P, tb, sq ) )
+		return false;
+	if( !rmd_chk_sites( P, tb, sq ) )
+		return false;
+	unsigned long long	slot = 0;
+	if( lane_id == 0 )
+		slot = atomicAdd( count, 1ull );
+	slot = __shfl( slot, 0 );
+	if( slot < ( unsigned long long )cap ){
+		int32_t	*w = hits + slot * P->hit_stride;		// (rmd_fill_hit's layout)
+		const int	k = RMA_HIT_HDR + 4 * P->n_elems;
+		if( lane_id == 0 ){
+			w[ 0 ] = seq;
+			w[ 1 ] = comp;
+			w[ 2 ] = z;
+			w[ 3 ] = rank;
+			w[ 4 ] = order;
+			w[ k + 0 ] = P->has_lctx ? tb.l_off : 0;
+			w[ k + 1 ] = P->has_lctx ? tb.l_len : 0;
+			w[ k + 2 ] = P->has_rctx ? tb.r_off : 0;
+			w[ k + 3 ] = P->has_rctx ? tb.r_len : 0;
+		}
+#pragma unroll
+		for( int s = 0; s < 2; s++ ){
+			const int	e = lane_id + 64 * s;
+			if( e < P->n_elems ){
+				w[ RMA_HIT_HDR + 4 * e + 0 ] = tb.moff[ s ];
+				w[ RMA_HIT_HDR + 4 * e + 1 ] = tb.mlen[ s ];
+				w[ RMA_HIT_HDR + 4 * e + 2 ] = tb.mpr[ s ];
+				w[ RMA_HIT_HDR + 4 * e + 3 ] = tb.mm[ s ];
+			}
+		}
+		for( int e = lane_id; e < P->n_efn; e += 64 )
+			w[ k + 4 + e ] = RMA_EFN_INFINITY;	// filled by the efn pass
+	}
+	return true;
+}
+
+// The matches the lanes of a wave have pending after a step (rmd_lean_t::pending), one at a time;
+// sq_of( l ): the sequence view lane l searches in.  Called by all 64 lanes.
+template< int BLOCK, class SQOF >
+__device__ inline void wave_emit_pending( const rmd_program_t *P, const LdsRecs<BLOCK> &lr, rmd_lean_t &st, int k, const SQOF &sq_of,
+	int seq, int comp, const HitBuf &hb, int lane_id, int order_base = 0 )
+{
+	for( unsigned long long em = __ballot( k >= 0 && st.pending ); em; em &= em - 1 ){
+		const int	l = __ffsll( em ) - 1;
+		const LdsRecs<BLOCK>	lrl{ lr.lo + ( l - lane_id ), lr.hi + ( l - lane_id ) };
+		if( lane_id == l && st.only_hl >= 0 && st.order >= ( 1 << PIECE_ORDER_BITS ) )
+			atomicMax( hb.ticket + 2, 1ull );	// (the pieces' order words would run into each other)
+		const bool	stored = wave_emit<BLOCK>( P, lrl, sq_of( l ), __shfl( st.szero, l ), __shfl( st.slen, l ), __shfl( st.rank, l ),
+			__shfl( st.order + order_base, l ), __shfl( seq, l ), __shfl( comp, l ), hb.hits, hb.count, hb.cap, lane_id );
+		if( lane_id == l ){
+			st.order += stored;
+			st.pending = 0;
+		}
+	}
+}
+
+// The lanes with `over` set search the item ( szero, r0, cnt ) each has got, start to end (what a tile's pass
+// A does with items that found room neither in the queue nor in its spill area; rare, kept out of line).
+// Called by all 64 lanes.
+template< int BLOCK >
+__device__ __noinline__ void lean_search_here( const rmd_program_t *P, uint32_t *lo, uint16_t *hi, const uint8_t *sq_bytes, int sq0,
+	bool over, int szero, int slen, int r0, int cnt, int seq, int comp, int32_t *hits, unsigned long long *count, long long cap, int lane_id )
+{
+	LdsRecs<BLOCK>	lr{ lo, hi };
+	const rmd_seq_t	sq{ sq_bytes, sq0 };
+	HitBuf	hb{};
+	hb.hits = hits;
+	hb.count = count;
+	hb.cap = cap;
+	DevSink	sink{ hb, seq, comp, P->hit_stride };
+	rmd_lean_t	st;
+	int	k = -1;
+	if( over )
+		k = rmd_lean_begin( P, lr, st, szero, slen, r0, cnt );
+	while( __ballot( k >= 0 ) ){
+		if( k >= 0 )
+			k = rmd_lean_step<LdsRecs<BLOCK>, DevSink, rmd_seq_t, rmd_no_accel_t, true>( P, lr, st, sq, k, nullptr, sink );
+		wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int ){ return sq; }, seq, comp, hb, lane_id );
+	}
+}
+
 // General path records of one lane in LDS (rmd_grec_t, 12 bytes per level): three dwords at
 // w[ ( 3 * k + j ) * BLOCK ], lane-contiguous, so a wave's access is conflict free whatever
 // levels its lanes are on.  Dword 0: window start | saved window end; dword 1: next end position |
@@ -414,6 +591,186 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 			}
 		}
 
+// ---------------------------------------------------------------- pooled pass B: one item
+// A lane takes pool item e (RMK_POOL_WORDS words: entry, start position, rank | strand << 16, the 3' ends
+// left to the first helix of the interior for two outer lengths): its window, four bits a base, from the
+// packed database into the lane's column of LDS (dwords STRIDE apart), the search state at its first
+// level.  Returns that level.
+template< int STRIDE, class LR >
+__device__ inline int pool_item_begin( const rmd_program_t *P, const DbView &db, const unsigned *e, uint32_t *col, int nib_max,
+	LR &lr, rmd_lean_t &st, rmd_nibseq_t<STRIDE> &nsq, int &seq_out, int &comp_out, int &order_base )
+{
+	const int	w = P->w_winsize, lm = P->lmargin, rm = P->rmargin;
+	const int	iseq = int( __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) );
+	const int	szero = int( __hip_atomic_load( e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) );
+	const unsigned	rc = __hip_atomic_load( e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+	const int	r = int( rc & 0xffffu ), icomp = int( rc >> 16 ) & 1;
+	const int	islen = db.slen[ iseq ];
+	const int64_t	off = db.base_off[ iseq ];
+	// the window's bases [ p0, p1 ) of the strand = [ f_lo, f_hi ) of the entry as stored
+	const int	p0 = rmd_imax( szero - lm, 0 ), p1 = rmd_imin( szero + w + rm, islen );
+	const int	f_lo = icomp ? islen - p1 : p0, f_hi = icomp ? islen - p0 : p1;
+	const int64_t	g0 = ( off + f_lo ) & ~int64_t( 7 );
+	const int	n_dw = int( ( off + f_hi - g0 + 7 ) >> 3 );
+	for( int j = 0; j < n_dw && j < nib_max; j++ ){
+		const int64_t	g = g0 + 8 * j;		// eight bases: half a word of codes, a byte of the mask
+		const uint32_t	cw = ( db.codes[ g >> 4 ] >> ( ( g & 8 ) * 2 ) ) & 0xffffu;
+		const uint32_t	am = ( db.amask[ g >> 5 ] >> ( g & 24 ) ) & 0xffu;
+		uint32_t	x = ( cw | ( cw << 8 ) ) & 0x00ff00ffu;
+		x = ( x | ( x << 4 ) ) & 0x0f0f0f0fu;
+		x = ( x | ( x << 2 ) ) & 0x33333333u;
+		if( icomp )
+			x ^= 0x33333333u;		// (mk_rcmp, rnamot.c:193: 3 - code)
+		uint32_t	n = ( am | ( am << 12 ) ) & 0x000f000fu;
+		n = ( n | ( n << 6 ) ) & 0x03030303u;
+		n = ( n | ( n << 3 ) ) & 0x11111111u;
+		col[ j * STRIDE ] = ( x & ~( n * 3u ) ) | ( n << 2 );	// RMA_BC_N = 4
+	}
+	nsq.flip = icomp ? -1 : 0;
+	nsq.bias = int( off - g0 ) + ( icomp ? islen : 0 );
+	seq_out = iseq;
+	comp_out = icomp;
+	const int	k = rmd_lean_begin( P, lr, st, szero, islen, r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+	st.hmask[ 0 ] = __hip_atomic_load( e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+	st.hmask[ 1 ] = __hip_atomic_load( e + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+	st.hm_level = ( st.hmask[ 0 ] & st.hmask[ 1 ] ) == ~0u ? -1 : P->elems[ P->searches[ 0 ] ].head_s;
+	// a piece of an item (pool_sub_count): one length of the first element, one of the ends left to the first helix
+	// of its interior or all of them.  Its candidates' order words start where the walk of the whole item
+	// would have counted them at least: pieces in the order that walk takes them, lengths up, ends down.
+	const int	piece = int( rc >> 17 ) & 3;
+	order_base = 0;
+	if( piece ){
+		const unsigned	m = st.hmask[ piece - 1 ];
+		st.only_hl = P->elems[ P->searches[ 0 ] ].minlen + piece - 1;
+		order_base = ( ( piece - 1 ) * 32 + ( __popc( m ) == 1 ? 31 - ( __ffs( int( m ) ) - 1 ) : 0 ) ) << PIECE_ORDER_BITS;
+	}
+	return k;
+}
+
+// The pieces pool item ( rank | strand, masks h0, h1 ) is cut into for the drain kernel's list; piece p of them
+// as the words 2 .. 4 of a list item.  An item whose masks say nothing (~0: no test was made) stays whole; one
+// with masks goes length by length of the first element -- that length's ends one by one when they are few
+// (each then is a walk of a handful of steps: the tail of the drain kernel is its longest walk, 159 steps
+// over trna.descr when items stay whole).
+#define POOL_SUB_ENDS	8
+__device__ inline int pool_sub_count( unsigned rc, unsigned h0, unsigned h1 )
+{
+	if( ( h0 & h1 ) == ~0u || ( rc & 0xffffu ) == 0xffffu )
+		return 1;
+	const int	c0 = h0 == 0 ? 0 : ( h0 == ~0u || __popc( h0 ) > POOL_SUB_ENDS ) ? 1 : __popc( h0 );
+	const int	c1 = h1 == 0 ? 0 : ( h1 == ~0u || __popc( h1 ) > POOL_SUB_ENDS ) ? 1 : __popc( h1 );
+	return c0 + c1;
+}
+__device__ inline void pool_sub_piece( unsigned rc, unsigned h0, unsigned h1, int p, unsigned *w2, unsigned *w3, unsigned *w4 )
+{
+	*w2 = rc;
+	*w3 = h0;
+	*w4 = h1;
+	if( ( h0 & h1 ) == ~0u || ( rc & 0xffffu ) == 0xffffu )
+		return;
+	const int	c0 = h0 == 0 ? 0 : ( h0 == ~0u || __popc( h0 ) > POOL_SUB_ENDS ) ? 1 : __popc( h0 );
+	const int	i = p < c0 ? 0 : 1;
+	unsigned	m = i == 0 ? h0 : h1;
+	if( !( m == ~0u || __popc( m ) > POOL_SUB_ENDS ) ){
+		// its ( p - first )-th end, from the highest down
+		for( int q = i == 0 ? p : p - c0; q > 0; q-- )
+			m &= ~( 1u << ( 31 - __clz( int( m ) ) ) );
+		m = 1u << ( 31 - __clz( int( m ) ) );
+	}
+	*w2 = rc | ( unsigned( i + 1 ) << 17 );
+	*w3 = i == 0 ? m : 0u;
+	*w4 = i == 0 ? 0u : m;
+}
+
+// The drain of the pooled instance.  The search kernel leaves the items that passed its tests in ONE list
+// in HBM (HitBuf::glist; a workgroup's pool is flushed there) instead of walking them itself: some twenty
+// per workgroup over trna.descr and 100 Mbases, each a walk of tens of microseconds with a heavy tail -- a
+// workgroup that walked its own kept the device waiting for 0.7 ms after the last tile was done
+// (RNAMOTIF_DBG bit 1048576).  This kernel comes after it on the same stream: workgroups of ONE wave (no
+// barrier anywhere), every wave taking its fair share of the list, then more as lanes come free.
+#define DRAIN_BLOCK	64
+#define DRAIN_NIB	32	// window dwords per lane (the host has checked the descriptor's window against it)
+template< int BLOCK >
+__global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
+rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb, int dbg )
+{
+	static_assert( BLOCK == 64, "one wave per workgroup" );
+	extern __shared__ __align__( 16 ) unsigned char	smem[];
+	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
+	const int	tid = threadIdx.x, lane_id = tid & 63;
+	for( unsigned i = tid; i < unsigned( prog_bytes ) / 4; i += BLOCK )
+		reinterpret_cast<uint32_t *>( P )[ i ] = reinterpret_cast<const uint32_t *>( gP )[ i ];
+	__syncthreads();
+	uint32_t	*const col = reinterpret_cast<uint32_t *>( smem + prog_bytes ) + tid;
+	uint32_t	*const lean_lo = reinterpret_cast<uint32_t *>( smem + prog_bytes ) + DRAIN_NIB * BLOCK;
+	uint16_t	*const lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
+	LdsRecs<BLOCK>	lr{ lean_lo + tid, lean_hi + tid };
+	const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
+	const long long	reserved = ( long long )__hip_atomic_load( hb.ticket + ( RMK_GCTL - 1 ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+	const long long	total = reserved < hb.glist_cap ? reserved : hb.glist_cap;
+	const long long	n_waves = ( long long )gridDim.x;
+	const long long	share = ( total + n_waves - 1 ) / n_waves;
+	const int	fair = share < 1 ? 1 : share > 64 ? 64 : int( share );
+	const int	refill = rmd_imax( 1, rmd_imin( hb.pool_refill, fair / 2 ) );
+	rmd_nibseq_t<BLOCK>	nsq{ col, 0, 0 };
+	rmd_lean_t	st;
+	DevSink	sink{ hb, 0, 0, P->hit_stride };
+	const rmd_no_accel_t	none;
+	int	k = -1, n_steps = 0, n_emit = 0, obase = 0;
+	unsigned long long	t_item = 0;
+	bool	dry = total == 0;
+	for( ; ; ){
+		const unsigned long long	want = __ballot( k < 0 && !dry );
+		const unsigned long long	busy = __ballot( k >= 0 );
+		// lanes that came free take items once enough of them have (a round costs the wave the same for one
+		// lane as for sixteen), and no more than leaves the other waves their share
+		const int	n = rmd_imin( __popcll( want ), fair - __popcll( busy ) );
+		if( n > 0 && ( busy == 0 || n >= refill ) ){
+			unsigned long long	base = 0;
+			if( lane_id == __ffsll( want ) - 1 )
+				base = atomicAdd( hb.ticket + RMK_GCTL, ( unsigned long long )n );
+			base = __shfl( base, __ffsll( want ) - 1 );
+			if( k < 0 && !dry ){
+				const long long	i = ( long long )base + __popcll( want & lt_mask );
+				if( i < ( long long )base + n && i < total ){
+					const unsigned	*e = hb.pool + RMK_POOL_WORDS * size_t( i );
+					// (a workgroup whose items found no room in the list left its share of it void)
+					if( __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) != 0xffffffffu ){
+						k = pool_item_begin<BLOCK>( P, db, e, col, DRAIN_NIB, lr, st, nsq, sink.seq, sink.comp, obase );
+						t_item = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
+						n_steps = n_emit = 0;
+					}
+				}else if( ( long long )base + n >= total )
+					dry = true;
+			}
+			continue;
+		}
+		if( busy == 0 )
+			break;
+		const bool	was = k >= 0;
+		if( k >= 0 ){
+			k = rmd_lean_step<LdsRecs<BLOCK>, DevSink, rmd_nibseq_t<BLOCK>, rmd_no_accel_t, true>( P, lr, st, nsq, k, nullptr, sink, none );
+			n_steps++;
+			n_emit += st.pending;
+		}
+		wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int l ){
+			return rmd_nibseq_t<BLOCK>{ nsq.w + ( l - lane_id ), __shfl( nsq.flip, l ), __shfl( nsq.bias, l ) }; },
+			sink.seq, sink.comp, hb, lane_id, obase );
+		if( ( dbg & 32 ) && was && k < 0 ){
+			// (diagnostic: how long the items take, how many steps, how many complete matches)
+			const unsigned long long	dt = __builtin_amdgcn_s_memtime() - t_item;
+			atomicAdd( hb.ticket + 23 + ( 63 - __clzll( dt | 1ull ) ), 1ull );
+			atomicMax( hb.ticket + 21, dt );
+			atomicAdd( hb.ticket + 20, dt );
+			atomicAdd( hb.ticket + 17, 1ull );
+			atomicAdd( hb.ticket + 18, ( unsigned long long )n_steps );
+			atomicMax( hb.ticket + 22, ( unsigned long long )n_steps );
+			atomicAdd( hb.ticket + 60 + rmd_imin( 31 - __clz( n_emit | 1 ) + ( n_emit > 0 ), 15 ), 1ull );
+			atomicAdd( hb.ticket + 76 + rmd_imin( 31 - __clz( n_emit | 1 ) + ( n_emit > 0 ), 15 ), dt );
+		}
+	}
+}
+
 // ---------------------------------------------------------------- search kernel
 // LEAN: the descriptor has only ss and proper helices (rmd_program_t::lean_ok) -- pass B keeps
 // 8 bytes of state per level in LDS; the general state machine is not compiled into that
@@ -450,7 +807,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const int	slot_bytes = ( tile_bytes + 15 ) & ~15;
 	__shared__ long long	s_tile;
 	__shared__ int	s_seq, s_qn, s_qhead, s_dqn, s_dqhead;
-	__shared__ int	s_pool_n, s_pool_head;
+	__shared__ int	s_pool_n, s_pool_head, s_glist_full, s_fl_total, s_fl_pos;
+	__shared__ long long	s_gstart;
 	__shared__ int	s_ctx[ G ][ G > 1 ? 8 : 1 ];	// G > 1: seq, comp, slen, z0, p_lo, vec_words of every slot
 	const int	tid = threadIdx.x;
 	// lanes that share a tile in pass A: the workgroup, or one wave per slot
@@ -463,6 +821,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	if( tid == 0 ){
 		s_pool_n = 0;
 		s_pool_head = 0;
+		s_glist_full = 0;
+		s_fl_total = 0;
+		s_fl_pos = 0;
 	}
 	__syncthreads();
 
@@ -502,7 +863,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// the chain's working vectors -- where each base stands (5), two groups' vectors, a stem-loop's cores --
 	// take the place of the search records, which are not in use before pass B
 	unsigned long long	*const tv = reinterpret_cast<unsigned long long *>( lean_lo );
-	const bool	chain_vecs = chain_on && size_t( P->n_searches ) * BLOCK * LEAN_REC_BYTES >= size_t( 8 ) * pb_words * sizeof( unsigned long long );
+	const bool	chain_vecs = chain_on && size_t( P->n_searches ) * BLOCK * LEAN_REC_BYTES >= size_t( 10 ) * pb_words * sizeof( unsigned long long );
+	__shared__ int	s_inplace;		// this tile's pre-filter searched queue overflow in place: the records, and with them tv, were written
 	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
 	// (the general instance's records take the same place; behind them the resume states of the
 	// levels up to the split level and the queue of continuations)
@@ -563,6 +925,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	long long	t_next = 0;
 	if( tid == 0 )
 		t_next = ( long long )atomicAdd( hb.ticket, 1ull );
+	bool	had_tiles = false;
+	if( ( dbg & 1048576 ) && tid == 0 )
+		atomicMax( hb.ticket + 88, ~( unsigned long long )wall_clock64() );	// (the first workgroup's start)
 	for( ; ; ){
 		if( tid == 0 ){
 			const long long	t = t_next;
@@ -585,7 +950,12 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				last = true;
 			else
 				break;
-		}
+			if( ( dbg & 1048576 ) && tid == 0 && had_tiles ){
+				atomicAdd( hb.ticket + 89, ( unsigned long long )wall_clock64() );	// (out of tiles)
+				atomicAdd( hb.ticket + 87, 1ull );
+			}
+		}else
+			had_tiles = true;
 		// what pass B needs of the tile (G > 1: of the last slot; pass B reloads per item)
 		int	seq = 0, slen = 0, z0 = 0, p_lo = 0, vec_words = 0;
 		uint8_t	*tile = tile0;
@@ -773,6 +1143,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 #define QPUSH( pred, item, szero_, r0_, cnt_ )	do{ \
 		const unsigned long long	m_ = __ballot( pred ); \
 		if( m_ ){ \
+			bool	over_ = false; \
 			int	base_ = 0; \
 			if( lane_id == __ffsll( m_ ) - 1 ) \
 				base_ = atomicAdd( &s_qn, __popcll( m_ ) ); \
@@ -783,13 +1154,16 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					queue[ slot_ ] = ( item ) | slot_bits; \
 				else if( slot_ < qtotal ) \
 					spill[ slot_ - qcap ] = ( item ) | slot_bits; \
-				else if constexpr( LEAN ){ \
-					rmd_lean_t	st_; \
-					int	k_ = rmd_lean_begin( P, lr, st_, szero_, slen, r0_, cnt_ ); \
-					while( k_ >= 0 ) \
-						k_ = rmd_lean_step( P, lr, st_, sq, k_, &lane, sink ); \
-				} \
+				else \
+					over_ = true; \
 				/* (general instance: the launch is repeated with a spill area that holds the tile's items) */ \
+			} \
+			if constexpr( LEAN ){ \
+				if( __ballot( over_ ) ){ \
+					/* items beyond the queue and its spill area are searched here and now */ \
+					s_inplace = 1; \
+					lean_search_here<BLOCK>( P, lr.lo, lr.hi, sq.sq, sq.sq0, over_, szero_, slen, r0_, cnt_, sink.seq, sink.comp, hb.hits, hb.count, hb.cap, lane_id ); \
+				} \
 			} \
 		} }while( 0 )
 
@@ -868,8 +1242,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		}
 		// Look-ahead chain of the first element's interior (rmd_chain_t): start positions at which the
 		// interior's stem-loops cannot all be there are not searched.  tv[ 0 .. 4 ]: where each base stands;
-		// tv[ 5 ], tv[ 6 ]: a group's vector and the next group's, in turns; tv[ 7 ]: a stem-loop's cores;
-		// xv[ 0 ]: the start positions that remain.
+		// tv[ 5 ], tv[ 6 ]: a group's vector and the next group's, in turns; tv[ 7 ], tv[ 8 ]: the cores of the
+		// first two shapes of stem-loop (kept for pass A'), tv[ 9 ]: those of any other; xv[ 0 ]: the start
+		// positions that remain.
 		const bool	chain = chain_vecs && bitpar && !( dbg & 32768 );
 		if( chain ){
 			const rmd_chain_t	&C = P->chain;
@@ -887,14 +1262,17 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					m |= peek( tv + b * pb_words, x ) & peek( pb + b * pb_words, x + d );
 				return m;
 			};
-			int	cur = 0, core_key = -1;		// (stem-loops of one shape -- trna.descr's anticodon and T arms -- share their cores)
+			if( tid == 0 )
+				s_inplace = 0;
+			int	cur = 0, slot_key[ 3 ] = { -1, -1, -1 };		// (stem-loops of one shape -- trna.descr's anticodon and T arms -- share their cores)
 			for( int k = C.n - 1; k >= 0; k-- ){
 				const rmd_chain_sib_t	sb = C.sib[ k ];
-				unsigned long long	*const dst = tv + ( 5 + cur ) * pb_words, *const core = tv + 7 * pb_words;
+				const int	slot = sb.core_slot >= 0 ? sb.core_slot : 2;
+				unsigned long long	*const dst = tv + ( 5 + cur ) * pb_words, *const core = tv + ( 7 + slot ) * pb_words;
 				const unsigned long long	*const nxt = tv + ( 5 + ( cur ^ 1 ) ) * pb_words;
 				const int	key = ( int( sb.hmin ) << 20 ) | ( int( sb.lmin ) << 10 ) | int( sb.lmax );
-				if( sb.leaf && key != core_key ){
-					core_key = key;
+				if( sb.leaf && key != slot_key[ slot ] ){
+					slot_key[ slot ] = key;
 					// the innermost hmin pairs of the stem-loop, for one of its loop lengths
 					for( int wi = tid; wi < vec_words; wi += BLOCK ){
 						const int	x = wi * 64;
@@ -1225,12 +1603,14 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			// ---- pass A': every queued item takes the tail test (for every helix length its end
 			// position allows: is the pinned helix that closes the interior there?  nine in ten
 			// are not), all lanes busy; what passes goes to the pool with its entry and strand
-			unsigned	*const pool = hb.pool + size_t( blockIdx.x ) * hb.pool_cap * 3;
+			unsigned	*const pool = hb.pool + ( size_t( hb.glist_cap ) + size_t( blockIdx.x ) * hb.pool_cap ) * RMK_POOL_WORDS;
 			{
 				TailAccel	ac{ P, pb, tile, pb_words, p_lo, vec_words * 64, 0 };
+				// (the chain's cores are where it left them unless the pre-filter had to search in place)
+				const bool	head_next = chain_vecs && bitpar && P->chain.hn_on && !( dbg & ( 32768 | 262144 ) ) && !last && s_inplace == 0;
 				for( int c = 0; c < nq; c += BLOCK ){
 					const int	i = c + tid;
-					unsigned	item = 0;
+					unsigned	item = 0, hm[ 2 ] = { ~0u, ~0u };	// (the 3' ends left to the first helix of the interior, per outer length)
 					bool	keep = false;
 					if( i < nq ){
 						item = i < qcap ? queue[ i ] : __hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
@@ -1242,12 +1622,17 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 							rmd_level0_range( P, szero, slen, &hi, &lo );
 							const int	span = hi - r - szero + 1;
 							keep = false;
-							for( int hl = e0.minlen; hl <= e0.maxlen && !keep; hl++ ){
+							// (every outer length is looked at: each leaves its own ends to the interior's first helix)
+							const bool	want_masks = head_next && e0.head_pre_min == e0.head_pre_max;
+							if( want_masks )
+								hm[ 0 ] = hm[ 1 ] = 0;
+							for( int hl = e0.minlen; hl <= e0.maxlen && ( !keep || want_masks ); hl++ ){
 								const int	ilen = span - 2 * hl;
 								if( ilen < e0.minilen )
 									break;
 								if( ilen > e0.maxilen )
 									continue;
+								unsigned	ends_left = ~0u;
 								bool	ok = true, t;
 								if( tail_from_rows && ac.tail( e0, szero, hl, span - 1 - hl, &t ) )
 									ok = t;
@@ -1267,12 +1652,38 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 										// (undecided -- a range wider than a word, bits the vectors do not hold: kept)
 										if( top - bot >= 64 || q_hi - H.minlen < 0 || q_hi + 96 > vec_words * 64 )
 											ok = true;
-										else
-											ok = rows_win( pb, pb_words, tile, p_lo, H.minlen, lim, ( H.ends & RMA_5PAIRED ) != 0, s5, w0, bot ) != 0;
+										else{
+											unsigned long long	Wd = rows_win( pb, pb_words, tile, p_lo, H.minlen, lim, ( H.ends & RMA_5PAIRED ) != 0, s5, w0, bot );
+											if( Wd && head_next ){
+												// ... and one of those ends must have the next stem-loop's core at the right distance
+												// behind it (bit i of Wd: end w0 + i)
+												const rmd_chain_t	&C = P->chain;
+												unsigned long long	cw = 0;
+												bool	all = true;
+												for( int g = C.hn_glo + 1; g <= C.hn_ghi + 1 + C.hn_tmax; g++ ){
+													const int	x = w0 + g - p_lo + 64;
+													if( x < 0 || x + 96 > vec_words * 64 )
+														all = false;		// (undecided)
+													else
+														cw |= bits64( tv + ( 7 + C.hn_slot ) * pb_words, x );
+												}
+												if( all )
+													Wd &= cw;
+												// (bit j of the mask: end bot + j)
+												if( all && top - bot < 32 )
+													ends_left = unsigned( Wd >> ( bot - w0 ) );
+											}
+											ok = Wd != 0;
+										}
 									}
 								}
-								keep = ok;
+								if( ok && hl - e0.minlen < 2 )
+									hm[ hl - e0.minlen ] = want_masks ? ends_left : ~0u;
+								if( ok && hl - e0.minlen >= 2 )
+									hm[ 0 ] = hm[ 1 ] = ~0u, keep = true;		// (a third length: no room for its mask; no restriction)
+								keep = keep || ok;
 							}
+							// (a length that failed its tests keeps the mask 0: the walk finds nothing there either way)
 						}
 					}
 					const unsigned long long	m = __ballot( keep );
@@ -1284,7 +1695,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						if( keep ){
 							// (at most pool_min - 1 items wait when a tile starts and a tile queues at most
 							// qtotal: the pool holds pool_min + qtotal)
-							unsigned	*e = pool + 3 * size_t( base + __popcll( m & lt_mask ) );
+							unsigned	*e = pool + RMK_POOL_WORDS * size_t( base + __popcll( m & lt_mask ) );
+							e[ 3 ] = hm[ 0 ];
+							e[ 4 ] = hm[ 1 ];
 							e[ 0 ] = unsigned( seq );
 							e[ 1 ] = unsigned( z0 + int( item >> 16 ) );
 							e[ 2 ] = ( item & 0xffffu ) | ( unsigned( sink.comp ) << 16 );
@@ -1294,6 +1707,66 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			}
 			PHASE( 3 );
 			__syncthreads();
+			// the workgroup's pool goes to the device-wide list the drain kernel works on (rma_drain_kernel), now and
+			// then and at the end; only when that list is full the workgroup walks its items itself, as below
+			if( hb.glist_cap > 0 && s_glist_full == 0 && s_pool_n > 0 && ( last || s_pool_n >= GLIST_FLUSH ) ){
+				const int	n_fl = s_pool_n;
+				const bool	cut = !( dbg & 2097152 );		// (diagnostic: items go whole)
+				// how many list items the pool's make (pool_sub_count) ...
+				int	mine = 0;
+				for( int i = tid; i < n_fl; i += BLOCK ){
+					const unsigned	*e = pool + RMK_POOL_WORDS * size_t( i );
+					mine += !cut ? 1 : pool_sub_count( __hip_atomic_load( e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ),
+						__hip_atomic_load( e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ), __hip_atomic_load( e + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) );
+				}
+				if( mine )
+					atomicAdd( &s_fl_total, mine );
+				__syncthreads();
+				// ... their place in the list, all or none ...
+				if( tid == 0 )
+					s_gstart = ( long long )atomicAdd( hb.ticket + ( RMK_GCTL - 1 ), ( unsigned long long )s_fl_total );
+				__syncthreads();
+				const long long	g0 = s_gstart;
+				const int	n_list = s_fl_total;
+				const bool	fits = g0 + n_list <= hb.glist_cap;
+				if( fits ){
+					// ... and the pieces, in whatever order the lanes get to them
+					for( int i = tid; i < n_fl; i += BLOCK ){
+						const unsigned	*e = pool + RMK_POOL_WORDS * size_t( i );
+						const unsigned	w0 = __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ), w1 = __hip_atomic_load( e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+						const unsigned	rc = __hip_atomic_load( e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+						const unsigned	h0 = __hip_atomic_load( e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ), h1 = __hip_atomic_load( e + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+						const int	n_p = !cut ? 1 : pool_sub_count( rc, h0, h1 );
+						if( n_p == 0 )
+							continue;
+						const int	at = atomicAdd( &s_fl_pos, n_p );
+						for( int p = 0; p < n_p; p++ ){
+							unsigned	*o = hb.pool + ( g0 + at + p ) * RMK_POOL_WORDS;
+							o[ 0 ] = w0;
+							o[ 1 ] = w1;
+							if( cut )
+								pool_sub_piece( rc, h0, h1, p, o + 2, o + 3, o + 4 );
+							else
+								o[ 2 ] = rc, o[ 3 ] = h0, o[ 4 ] = h1;
+						}
+					}
+				}else{
+					// no room: what was reserved of the list stays void, the workgroup walks its items itself from now on
+					const int	n_void = hb.glist_cap > g0 ? int( hb.glist_cap - g0 < n_list ? hb.glist_cap - g0 : n_list ) : 0;
+					for( int i = tid; i < n_void; i += BLOCK )
+						hb.pool[ ( g0 + i ) * RMK_POOL_WORDS ] = 0xffffffffu;
+				}
+				__syncthreads();
+				if( tid == 0 ){
+					if( fits )
+						s_pool_n = 0;
+					else
+						s_glist_full = 1;
+					s_fl_total = 0;
+					s_fl_pos = 0;
+				}
+				__syncthreads();
+			}
 			const int	n_pool = s_pool_n;
 			if( n_pool > 0 && ( last || n_pool >= hb.pool_min ) && ( dbg & 2048 ) ){
 				// (diagnostic: the pool is filled and thrown away)
@@ -1305,6 +1778,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				constexpr int	NIB_MAX = 32;		// window dwords per lane the host has checked room for
 				uint32_t	*const col = reinterpret_cast<uint32_t *>( tile0 ) + tid;
 				rmd_nibseq_t<BLOCK>	nsq{ col, 0, 0 };
+				unsigned long long	t_wave = 0;
 				rmd_lean_t	st;
 				const rmd_no_accel_t	none;
 				for( ; ; ){
@@ -1313,6 +1787,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					// idle lanes pop together: a window costs some hundred instructions to rebuild, and
 					// a round for one lane costs the wave as much as a round for sixteen
 					if( want && ( busy == 0 || __popcll( want ) >= hb.pool_refill ) ){
+						const unsigned long long	t_p0 = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
 						if( ( dbg & 32 ) && lane_id == 0 ){
 							atomicAdd( hb.ticket + 15, 1ull );
 							atomicAdd( hb.ticket + 16, ( unsigned long long )__popcll( want ) );
@@ -1324,50 +1799,51 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						if( k < 0 && !dry ){
 							const int	i = base + __popcll( want & lt_mask );
 							if( i < n_pool ){
-								const unsigned	*e = pool + 3 * size_t( i );
-								const int	iseq = int( __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) );
-								const int	szero = int( __hip_atomic_load( e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) );
-								const unsigned	rc = __hip_atomic_load( e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-								const int	r = int( rc & 0xffffu ), icomp = int( rc >> 16 ) & 1;
-								const int	islen = db.slen[ iseq ];
-								const int64_t	off = db.base_off[ iseq ];
-								// the window's bases [ p0, p1 ) of the strand = [ f_lo, f_hi ) of the entry as stored
-								const int	p0 = rmd_imax( szero - lm, 0 ), p1 = rmd_imin( szero + w + rm, islen );
-								const int	f_lo = icomp ? islen - p1 : p0, f_hi = icomp ? islen - p0 : p1;
-								const int64_t	g0 = ( off + f_lo ) & ~int64_t( 7 );
-								const int	n_dw = int( ( off + f_hi - g0 + 7 ) >> 3 );
-								for( int j = 0; j < n_dw && j < NIB_MAX; j++ ){
-									const int64_t	g = g0 + 8 * j;		// eight bases: half a word of codes, a byte of the mask
-									const uint32_t	cw = ( db.codes[ g >> 4 ] >> ( ( g & 8 ) * 2 ) ) & 0xffffu;
-									const uint32_t	am = ( db.amask[ g >> 5 ] >> ( g & 24 ) ) & 0xffu;
-									uint32_t	x = ( cw | ( cw << 8 ) ) & 0x00ff00ffu;
-									x = ( x | ( x << 4 ) ) & 0x0f0f0f0fu;
-									x = ( x | ( x << 2 ) ) & 0x33333333u;
-									if( icomp )
-										x ^= 0x33333333u;		// (mk_rcmp, rnamot.c:193: 3 - code)
-									uint32_t	n = ( am | ( am << 12 ) ) & 0x000f000fu;
-									n = ( n | ( n << 6 ) ) & 0x03030303u;
-									n = ( n | ( n << 3 ) ) & 0x11111111u;
-									col[ j * BLOCK ] = ( x & ~( n * 3u ) ) | ( n << 2 );	// RMA_BC_N = 4
-								}
-								nsq.flip = icomp ? -1 : 0;
-								nsq.bias = int( off - g0 ) + ( icomp ? islen : 0 );
-								sink.seq = iseq;
-								sink.comp = icomp;
-								k = rmd_lean_begin( P, lr, st, szero, islen, r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+								int	whole;		// (the workgroup's own items are whole: their order words start at 0)
+								k = pool_item_begin<BLOCK>( P, db, pool + RMK_POOL_WORDS * size_t( i ), col, NIB_MAX, lr, st, nsq, sink.seq, sink.comp, whole );
 							}else
 								dry = true;
 						}
+						if( ( dbg & 32 ) && lane_id == 0 )
+							atomicAdd( hb.ticket + 19, __builtin_amdgcn_s_memtime() - t_p0 );
 						continue;
 					}
 					if( busy == 0 )
 						break;
+					const unsigned long long	t_s0 = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
 					if( ( dbg & 32 ) && lane_id == 0 ){
 						atomicAdd( hb.ticket + 17, 1ull );
 						atomicAdd( hb.ticket + 18, ( unsigned long long )__popcll( busy ) );
 					}
+					// (diagnostic: the deepest level any lane of the wave steps at)
+					int	k_in_ = 0;
+					if( dbg & 32 ){
+						k_in_ = k;
+						for( int o = 32; o > 0; o >>= 1 )
+							k_in_ = rmd_imax( k_in_, __shfl_xor( k_in_, o ) );
+					}
 					if( k >= 0 )
-						k = rmd_lean_step( P, lr, st, nsq, k, &lane, sink, none );
+						k = rmd_lean_step<LdsRecs<BLOCK>, DevSink, rmd_nibseq_t<BLOCK>, rmd_no_accel_t, true>( P, lr, st, nsq, k, &lane, sink, none );
+					// complete matches, one at a time, the whole wave on each
+					const unsigned long long	t_e0 = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
+					const int	n_em_ = ( dbg & 32 ) ? __popcll( __ballot( k >= 0 && st.pending ) ) : 0;
+					wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int l ){
+						return rmd_nibseq_t<BLOCK>{ nsq.w + ( l - lane_id ), __shfl( nsq.flip, l ), __shfl( nsq.bias, l ) }; },
+						sink.seq, sink.comp, hb, lane_id );
+					if( ( dbg & 32 ) && lane_id == 0 && n_em_ ){
+						atomicAdd( hb.ticket + 92, __builtin_amdgcn_s_memtime() - t_e0 );
+						atomicAdd( hb.ticket + 93, ( unsigned long long )n_em_ );
+					}
+					if( ( dbg & 32 ) && lane_id == 0 ){
+						const unsigned long long	dt_ = __builtin_amdgcn_s_memtime() - t_s0;
+						atomicAdd( hb.ticket + 20, dt_ );
+						atomicMax( hb.ticket + 21, dt_ );		// the longest single step
+						atomicAdd( hb.ticket + 23 + ( 63 - __clzll( dt_ | 1ull ) ), 1ull );
+						atomicAdd( hb.ticket + 60 + rmd_imin( rmd_imax( k_in_, 0 ), 15 ), dt_ );
+						atomicAdd( hb.ticket + 76 + rmd_imin( rmd_imax( k_in_, 0 ), 15 ), 1ull );
+						t_wave += dt_;
+						atomicMax( hb.ticket + 22, t_wave );	// the most any wave spent stepping
+					}
 				}
 				__syncthreads();
 				if( tid == 0 ){
@@ -1377,6 +1853,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			}
 			if( last ){
 				PHASE( 4 );
+				if( ( dbg & 1048576 ) && tid == 0 && had_tiles ){
+					atomicMax( hb.ticket + 90, ( unsigned long long )wall_clock64() );
+					atomicAdd( hb.ticket + 91, ( unsigned long long )wall_clock64() );
+				}
 				break;
 			}
 		}else if constexpr( LEAN ){
@@ -1459,7 +1939,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( busy == 0 )
 					break;
 				if( k >= 0 )
-					k = rmd_lean_step( P, lr, st, sq, k, &lane, sink, accel );
+					k = rmd_lean_step<LdsRecs<BLOCK>, DevSink, rmd_seq_t, TailAccel, true>( P, lr, st, sq, k, &lane, sink, accel );
+				wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int l ){
+					return rmd_seq_t{ tile0 + __shfl( int( sq.sq - tile0 ), l ), __shfl( sq.sq0, l ) }; },
+					sink.seq, sink.comp, hb, lane_id );
 				if( ( dbg & 32 ) && lane_id == 0 )
 					atomicAdd( hb.ticket + 20, __builtin_amdgcn_s_memtime() - t_b1 );
 			}
@@ -1531,5 +2014,16 @@ hipError_t name_( int grid, size_t lds, hipStream_t s, const rmk_search_args &a 
 		return e; \
 	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( BLOCK_ ), lds, s, \
 		a.d_prog, a.prog_bytes, a.qcap, a.db, a.hb, a.tile_bytes, a.dbg ); \
+	return hipGetLastError(); \
+}
+
+#define RMK_DEFINE_DRAIN_LAUNCHER( name_ ) \
+hipError_t name_( int grid, size_t lds, hipStream_t s, const rmk_search_args &a ) \
+{ \
+	auto	kernel = &rma_drain_kernel<DRAIN_BLOCK>; \
+	hipError_t	e = hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ); \
+	if( e != hipSuccess ) \
+		return e; \
+	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( DRAIN_BLOCK ), lds, s, a.d_prog, a.prog_bytes, a.db, a.hb, a.dbg ); \
 	return hipGetLastError(); \
 }

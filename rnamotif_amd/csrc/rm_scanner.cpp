@@ -136,6 +136,7 @@ struct Options {
 	int	dbg = 0;
 	int	pool = -1;		// -1: by the descriptor, 0: pass B tile by tile
 	int	pool_min = 1024, pool_refill = 48;
+	int	drain = 1;		// pooled instance: the items are walked by a kernel of their own (0: by the workgroup that found them)
 	int	host_sort = 0, timing = 0;
 	int	short_force = -1;	// -1: by the mean entry length, 0 never, 1 always groups of small tiles
 	int	tile = 0, qcap = 0;	// forced tile size / queue entries, 0: computed
@@ -152,6 +153,7 @@ struct Options {
 		pool = env_int( "RNAMOTIF_POOL", -1 );
 		pool_min = std::max( 1, env_int( "RNAMOTIF_POOL_MIN", 1024 ) );
 		pool_refill = env_int( "RNAMOTIF_POOL_REFILL", 48 );
+		drain = env_int( "RNAMOTIF_DRAIN", 1 );
 		host_sort = env_int( "RNAMOTIF_HOSTSORT", 0 );
 		timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
 		if( const char *f = getenv( "RNAMOTIF_SHORT" ) )
@@ -201,6 +203,8 @@ struct rma_scanner {
 	unsigned long long	*d_counters = nullptr;	// [0] count, [1] ticket
 	unsigned	*d_spill = nullptr;		// [grid_blocks][spill_cap] queue overflow of every workgroup
 	int	spill_cap = 0;
+	bool	whole_items = false;		// ... which takes the items whole, not in pieces (see search_finish)
+	int	glist_cap = 0;			// pooled instance: items of the list the drain kernel walks (the head of d_pool)
 	unsigned	*d_pool = nullptr;		// [grid_blocks][pool_cap][3] pooled instance: items waiting for pass B
 	int	pool_cap = 0;
 	int32_t	*h_raw = nullptr;		// pinned
@@ -210,6 +214,8 @@ struct rma_scanner {
 	rma::DevHitSort	dsort;		// ordering on the device (rm_hitsort_dev.h)
 	unsigned long long	*h_ctr = nullptr;	// pinned: the counters a launch leaves
 	int	tile_t = 2048;
+	int	drain_grid = 0;
+	size_t	drain_lds = 0;
 	int	grid_blocks = 0;		// most workgroups of a launch of a lean instance (eight of four waves per CU)
 	int	spill_blocks = 0;		// workgroups d_spill has areas for
 	int	kinds = 0;			// RMD_KIND_* of the descriptor
@@ -378,7 +384,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		HIPCHK( hipMalloc( &sc->d_prog, size_t( sc->prog_bytes ) ) );
 		HIPCHK( hipMemcpy( sc->d_prog, img.data(), size_t( sc->prog_bytes ), hipMemcpyHostToDevice ) );
 	}
-	HIPCHK( hipMalloc( &sc->d_counters, 96 * sizeof( unsigned long long ) ) );
+	HIPCHK( hipMalloc( &sc->d_counters, RMK_N_COUNTERS * sizeof( unsigned long long ) ) );
 	if( efn != nullptr ){
 		std::vector<int16_t>	t16;
 		std::vector<int32_t>	tlkey;
@@ -508,12 +514,13 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 	else if( n == "pool" ) o.pool = value;
 	else if( n == "pool_min" ) o.pool_min = std::max( 1, value );
 	else if( n == "pool_refill" ) o.pool_refill = value;
+	else if( n == "drain" ) o.drain = value;
 	else if( n == "host_sort" ) o.host_sort = value;
 	else if( n == "timing" ) o.timing = value;
 	else if( n == "short" ) o.short_force = value;
 	else{
 		snprintf( err, errlen, "rma_scanner_set_option: no option '%s' that can change after creation "
-			"(dbg, pool, pool_min, pool_refill, host_sort, timing, short)", n.c_str() );
+			"(dbg, pool, pool_min, pool_refill, drain, host_sort, timing, short)", n.c_str() );
 		return 1;
 	}
 	return 0;
@@ -940,18 +947,21 @@ static DbView view_of( const rma_db *db, const Layout *l )
 static int launch_search( rma_scanner_t *sc, char *err, size_t errlen )
 {
 	const rma_scanner::InFlight	&f = sc->fly;
-	HIPCHK( hipMemsetAsync( sc->d_counters, 0, 96 * sizeof( unsigned long long ), sc->stream ) );
+	HIPCHK( hipMemsetAsync( sc->d_counters, 0, RMK_N_COUNTERS * sizeof( unsigned long long ), sc->stream ) );
 	rmk_search_args	a;
 	a.d_prog = sc->d_prog;
 	a.prog_bytes = sc->prog_bytes;
 	a.qcap = f.lay->qcap;
 	a.db = view_of( f.db, f.lay );
+	const bool	drain = f.inst == RMK_LEAN_POOL && sc->glist_cap > 0;
 	a.hb = HitBuf{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap, sc->d_pool, sc->pool_cap,
-		sc->opt.pool_min, sc->opt.pool_refill };
+		sc->opt.pool_min, sc->opt.pool_refill, f.inst == RMK_LEAN_POOL ? sc->glist_cap : 0 };
 	a.tile_bytes = f.tile_bytes;
-	a.dbg = sc->opt.dbg;
+	a.dbg = sc->opt.dbg | ( sc->whole_items ? 2097152 : 0 );
 	HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 	HIPCHK( rmk_launch_search( f.inst, f.grid, f.lds, sc->stream, a ) );
+	if( drain )	// the items the search kernel left in the list: walked by a kernel of their own
+		HIPCHK( rmk_launch_lean_drain( sc->drain_grid, sc->drain_lds, sc->stream, a ) );
 	HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 	// [0] candidates, [3] queue overflow of the general instance: one copy, one wait
 	HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->d_counters, 4 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, sc->stream ) );
@@ -967,15 +977,53 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 	( void )hipMemcpy( &q, sc->d_counters + 2, sizeof( q ), hipMemcpyDeviceToHost );
 	fprintf( stderr, "[dbg] queued items: %llu, candidates %llu (tile %d x %d, queue %d, LDS %zu, %lld tiles)\n", q, count,
 		f.lay->tile_t, f.grouped ? f.lay->group : 1, f.lay->qcap, f.lds, ( long long )f.lay->n_tiles );
+	if( ( dbg & 1048576 ) && f.lean ){
+		unsigned long long	tl[ 5 ];
+		( void )hipMemcpy( tl, sc->d_counters + 1 + 87, sizeof( tl ), hipMemcpyDeviceToHost );
+		const double	t0 = double( ~tl[ 1 ] ), g = double( tl[ 0 ] );
+		fprintf( stderr, "[dbg] workgroups that had tiles (%.0f of %d): out of tiles after %.1f us (mean), done after %.1f us (mean), %.1f us (last)\n", g, f.grid,
+			( double( tl[ 2 ] ) / g - t0 ) * 0.01, ( double( tl[ 4 ] ) / g - t0 ) * 0.01, ( double( tl[ 3 ] ) - t0 ) * 0.01 );
+	}
 	if( dbg & 32 ){
 		unsigned long long	ph[ 6 ];
 		( void )hipMemcpy( ph, sc->d_counters + 4, sizeof( ph ), hipMemcpyDeviceToHost );
 		double	tot = 0;
 		for( int i = 0; i < 6; i++ )
 			tot += double( ph[ i ] );
-		unsigned long long	lv[ 64 ];
+		unsigned long long	lv[ 80 ];
 		( void )hipMemcpy( lv, sc->d_counters + 16, sizeof( lv ), hipMemcpyDeviceToHost );
-		if( f.lean )
+		if( f.lean && !( f.inst == RMK_LEAN_POOL && sc->glist_cap > 0 ) )
+			fprintf( stderr, "[dbg] pool sessions: %.3g wave cycles popping (%.0f per round), %.3g stepping (%.0f per step)\n",
+				double( lv[ 4 ] ), lv[ 0 ] ? double( lv[ 4 ] ) / lv[ 0 ] : 0.0, double( lv[ 5 ] ), lv[ 2 ] ? double( lv[ 5 ] ) / lv[ 2 ] : 0.0 ),
+			fprintf( stderr, "[dbg] longest step %.3g cycles, most stepping in one wave (one session) %.3g cycles\n", double( lv[ 6 ] ), double( lv[ 7 ] ) );
+		if( f.inst == RMK_LEAN_POOL && sc->glist_cap > 0 ){
+			// (the drain kernel's items)
+			unsigned long long	g[ 2 ];
+			( void )hipMemcpy( g, sc->d_counters + RMK_GCTL, sizeof( g ), hipMemcpyDeviceToHost );
+			fprintf( stderr, "[dbg] drain: %llu items in the list (%llu taken), %llu walked: %.0f cycles and %.1f steps each; longest %.3g cycles, most steps %llu\n",
+				g[ 0 ], g[ 1 ], lv[ 2 ], lv[ 2 ] ? double( lv[ 5 ] ) / lv[ 2 ] : 0.0, lv[ 2 ] ? double( lv[ 3 ] ) / lv[ 2 ] : 0.0, double( lv[ 6 ] ), lv[ 7 ] );
+			fprintf( stderr, "[dbg] drain: items by log2( cycles ):" );
+			for( int b = 8; b < 32; b++ )
+				if( lv[ 8 + b ] )
+					fprintf( stderr, " %d:%llu", b, lv[ 8 + b ] );
+			fprintf( stderr, "\n[dbg] drain: items by complete matches (0, 1, 2-3, 4-7, ...: count, mean cycles):" );
+			for( int kk = 0; kk < 16; kk++ )
+				if( lv[ 45 + kk ] )
+					fprintf( stderr, " %llu,%.0f", lv[ 45 + kk ], double( lv[ 61 + kk ] ) / lv[ 45 + kk ] );
+			fprintf( stderr, "\n" );
+		}else if( f.lean ){
+			fprintf( stderr, "[dbg] steps by log2( cycles ):" );
+			for( int b = 8; b < 32; b++ )
+				if( lv[ 8 + b ] )
+					fprintf( stderr, " %d:%llu", b, lv[ 8 + b ] );
+			fprintf( stderr, "\n[dbg] complete matches: %llu, %.0f cycles each", lv[ 78 ], lv[ 78 ] ? double( lv[ 77 ] ) / lv[ 78 ] : 0.0 );
+			fprintf( stderr, "\n[dbg] steps by deepest level (count, mean cycles):" );
+			for( int kk = 0; kk < 16; kk++ )
+				if( lv[ 61 + kk ] )
+					fprintf( stderr, " %d:%llu,%.0f", kk, lv[ 61 + kk ], double( lv[ 45 + kk ] ) / lv[ 61 + kk ] );
+			fprintf( stderr, "\n" );
+		}
+		if( f.lean && !( f.inst == RMK_LEAN_POOL && sc->glist_cap > 0 ) )
 			fprintf( stderr, "[dbg] pass B: %llu pop rounds of %.1f lanes, %llu steps of %.1f lanes; wave cycles popping %.1f%%, stepping %.1f%%\n",
 				lv[ 0 ], lv[ 0 ] ? double( lv[ 1 ] ) / lv[ 0 ] : 0.0, lv[ 2 ], lv[ 2 ] ? double( lv[ 3 ] ) / lv[ 2 ] : 0.0,
 				100.0 * lv[ 4 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ), 100.0 * lv[ 5 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ) );
@@ -1048,15 +1096,24 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 			pooled = pooled && sc->opt.pool != 0;
 	}
 	if( pooled ){
+		// The list of the drain kernel: room for an item per 32 bases (trna.descr leaves one per 70 before the
+		// stem-loop tests and one per 4500 after them); a workgroup that finds it full walks its own items.
+		const int	want = !sc->opt.drain ? 0 : int( std::min<long long>( std::max<long long>( db->sum_slen / 32, 1 << 18 ), 1 << 24 ) );
 		const int	cap = sc->opt.pool_min + lay->qcap + sc->spill_cap;
-		if( cap > sc->pool_cap ){
+		if( cap > sc->pool_cap || want > sc->glist_cap || ( want == 0 && sc->glist_cap != 0 ) ){
 			HIPCHK( hipStreamSynchronize( sc->stream ) );
 			( void )hipFree( sc->d_pool );
 			sc->d_pool = nullptr;
-			sc->pool_cap = 0;
-			HIPCHK( hipMalloc( &sc->d_pool, size_t( sc->grid_blocks ) * cap * 3 * sizeof( unsigned ) ) );
-			sc->pool_cap = cap;
+			const int	cap1 = std::max( cap, sc->pool_cap );
+			sc->pool_cap = sc->glist_cap = 0;
+			HIPCHK( hipMalloc( &sc->d_pool, ( size_t( want ) + size_t( sc->grid_blocks ) * cap1 ) * RMK_POOL_WORDS * sizeof( unsigned ) ) );
+			sc->pool_cap = cap1;
+			sc->glist_cap = want;
 		}
+		// the drain kernel: one wave per workgroup -- the program, a window column and the records of 64 lanes
+		sc->drain_lds = size_t( sc->prog_bytes ) + size_t( 32 + dp.n_searches ) * 64 * sizeof( uint32_t ) + size_t( dp.n_searches ) * 64 * sizeof( uint16_t );
+		const int	per_cu = int( std::min<size_t>( 4 * SEARCH_WAVES_PER_SIMD, ( 160 * 1024 ) / ( sc->drain_lds + 64 ) ) );
+		sc->drain_grid = ( sc->grid_blocks / 8 ) * std::max( 1, per_cu );
 	}
 	// the kernel instance: lean (pooled, one tile or a group of small ones per pass), or the general one
 	// compiled for the kinds of element the descriptor has
@@ -1103,6 +1160,12 @@ static int search_finish( rma_scanner_t *sc, int64_t *n_hits, float *search_ms, 
 				HIPCHK( hipMalloc( &sc->d_spill, size_t( sc->spill_blocks ) * sc->spill_cap * sizeof( unsigned ) ) );
 				again = true;
 			}
+		}
+		if( f.lean && sc->h_ctr[ 3 ] != 0 && !sc->whole_items ){
+			// a piece of an item found more candidates than the order words of the pieces leave room for
+			// (PIECE_ORDER_BITS): once more, and from now on, with whole items
+			sc->whole_items = true;
+			again = true;
 		}
 		if( !again && int64_t( count ) > sc->hit_cap ){
 			if( attempt == 3 ){
