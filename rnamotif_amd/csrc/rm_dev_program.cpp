@@ -553,6 +553,39 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			}
 		}
 	}
+	// order words as numbers of the walk's choices (rmd_elem_t::ord_stride)
+	out->ord_ok = 0;
+	out->ord_bits = 0;
+	for( int d = 0; d < p->n_elems; d++ ){
+		out->elems[ d ].ord_stride = 0;
+		out->elems[ d ].ord_nlen = 1;
+		out->elems[ d ].ord_pad_ = 0;
+	}
+	if( out->lean_ok ){
+		long long	weight = 1;
+		bool	fits = true;
+		for( int s = p->n_searches - 1; s >= 0 && fits; s-- ){
+			rmd_elem_t	*d = &out->elems[ p->searches[ s ] ];
+			// (the first level's end position is the candidate's rank: no digit for it)
+			const long long	n_end = ( s == 0 || !d->loop ) ? 1 :
+				( d->maxglen == RMA_UNBOUNDED ? ( long long )out->w_winsize : ( long long )d->maxglen ) - d->minglen + 1;
+			const long long	n_len = d->type == RMA_T_SS ? 1 : ( long long )d->maxlen - d->minlen + 1;
+			if( n_end < 1 || n_len < 1 || n_len > 30000 )
+				fits = false;
+			else{
+				d->ord_stride = int32_t( weight );
+				d->ord_nlen = int16_t( n_len );
+				weight *= n_end * n_len;
+				if( weight > ( 1ll << 31 ) )
+					fits = false;
+			}
+		}
+		if( fits ){
+			out->ord_ok = 1;
+			while( ( 1ll << out->ord_bits ) < weight )
+				out->ord_bits++;
+		}
+	}
 	// the look-ahead chain of the first element's interior (rmd_chain_t)
 	memset( &out->chain, 0, sizeof( out->chain ) );
 	if( out->lean_ok ){

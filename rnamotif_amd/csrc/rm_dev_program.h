@@ -82,6 +82,14 @@ struct rmd_elem_t {
 	int8_t	head_s;			// helix: level of the first proper helix of its interior when only ss of bounded
 					// total length lie before it (its 5' start is pinned to the interior's start), else -1
 	int16_t	head_pre_min, head_pre_max;	// ... that total length
+	// lean path, head of a search level: the level's digit in the order word of a candidate.  The depth-first
+	// walk takes a level's end positions from the highest down and, at each, the helix lengths from the
+	// shortest up; so candidates of one start position and rank come in the order of the number whose digit at
+	// every level is ( first end - end ) * ord_nlen + ( length - minlen ), weight ord_stride (the levels
+	// below it multiplied out).  rmd_program_t::ord_ok says the number fits 31 bits; then the kernels store it
+	// as the order word and may walk an item in pieces, in any order (both sorts renumber the order words).
+	int32_t	ord_stride;
+	int16_t	ord_nlen, ord_pad_;
 };
 
 // First-tuple masks of a triplex / 4-plex pair table: match_triplex()/match_4plex() give up at
@@ -194,6 +202,7 @@ struct rmd_program_t {
 	int32_t	step_budget;		// general path: loop iterations a step may take before it pauses (>= 4)
 	int32_t	need_init;		// some helix is improper: element state must start UNDEF
 	int32_t	lean_ok;		// every level is ss or a proper helix: 8-byte-per-level search
+	int32_t	ord_ok, ord_bits;	// lean path: order words are numbers of the walk's choices (rmd_elem_t::ord_stride), of so many bits
 	int32_t	has_lctx, has_rctx;
 	int32_t	n_sites, n_efn;
 	int32_t	efn_usestdbp, efn_stdbp;

@@ -130,6 +130,7 @@ __device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, con
 {
 	// lane j: levels j and j + 64, as rmd_lean_emit's loop has them
 	int	lz[ 2 ] = { 0, 0 }, lc[ 2 ] = { 0, 0 }, lx[ 2 ] = { 0, 0 }, lm[ 2 ] = { 0, 0 };
+	int	digits = 0;	// (the levels' share of the order word, rmd_elem_t::ord_stride)
 #pragma unroll
 	for( int s = 0; s < 2; s++ ){
 		const int	kk = lane_id + 64 * s;
@@ -140,6 +141,10 @@ __device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, con
 			const int	zero = z + r.zero, cur = z + r.sd + 1;
 			lz[ s ] = zero;
 			lc[ s ] = cur;
+			{
+				const int	first = ( kk == 0 || !stp.loop ) ? int( r.sd ) + 1 : int( rmd_lean_open( P, kk, r.zero, r.osd ).sd );
+				digits += ( ( first - ( int( r.sd ) + 1 ) ) * stp.ord_nlen + ( stp.type == RMA_T_SS ? 0 : int( r.hl ) - stp.minlen ) ) * stp.ord_stride;
+			}
 			if( stp.type == RMA_T_SS ){
 				int	mm = 0;
 				if( stp.re >= 0 && stp.mismatch > 0 )
@@ -175,6 +180,11 @@ __device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, con
 		tb.mlen[ s ] = !placed ? 0 : ty == RMA_T_SS ? cur - zero + 1 : hl;
 		tb.mpr[ s ] = !placed || ty == RMA_T_SS ? 0 : x >> 8;
 		tb.mm[ s ] = !placed ? 0 : ty == RMA_T_H3 ? ( m >> 16 ) : int( int16_t( m & 0xffff ) );
+	}
+	if( P->ord_ok ){
+		for( int o = 32; o > 0; o >>= 1 )
+			digits += __shfl_xor( digits, o );
+		order = digits;
 	}
 	tb.slen = slen;
 	tb.l_mm = tb.r_mm = RMD_UNDEF;
@@ -716,7 +726,8 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 	rmd_lean_t	st;
 	DevSink	sink{ hb, 0, 0, P->hit_stride };
 	const rmd_no_accel_t	none;
-	int	k = -1, n_steps = 0, n_emit = 0, obase = 0;
+	int	k = -1, n_steps = 0, n_emit = 0, obase = 0, floor_ = 0;
+	const bool	forks = P->ord_ok && !( dbg & 4194304 );
 	unsigned long long	t_item = 0;
 	bool	dry = total == 0;
 	for( ; ; ){
@@ -737,6 +748,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 					// (a workgroup whose items found no room in the list left its share of it void)
 					if( __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) != 0xffffffffu ){
 						k = pool_item_begin<BLOCK>( P, db, e, col, DRAIN_NIB, lr, st, nsq, sink.seq, sink.comp, obase );
+						floor_ = 0;
 						t_item = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
 						n_steps = n_emit = 0;
 					}
@@ -748,6 +760,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 		if( busy == 0 )
 			break;
 		const bool	was = k >= 0;
+		const int	k_was = k;
 		if( k >= 0 ){
 			k = rmd_lean_step<LdsRecs<BLOCK>, DevSink, rmd_nibseq_t<BLOCK>, rmd_no_accel_t, true>( P, lr, st, nsq, k, nullptr, sink, none );
 			n_steps++;
@@ -756,6 +769,65 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 		wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int l ){
 			return rmd_nibseq_t<BLOCK>{ nsq.w + ( l - lane_id ), __shfl( nsq.flip, l ), __shfl( nsq.bias, l ) }; },
 			sink.seq, sink.comp, hb, lane_id, obase );
+		if( k >= 0 && k < floor_ )
+			k = -1;		// (the subtree this lane was given is done)
+		if( forks ){
+			// Lanes with nothing left to take are given subtrees: a lane that has just gone down a level hands
+			// that level's walk -- its records, window and state, copied -- to an idle lane and goes on with the
+			// alternatives of its own level, as if the subtree had been walked.  (The candidates' order words do
+			// not depend on who finds them when: rmd_elem_t::ord_stride.)  The longest walk of trna.descr's
+			// items, 73 steps one after the other, is what the drain kernel took its time from.
+			const unsigned long long	idle = __ballot( k < 0 && dry );
+			const unsigned long long	down = __ballot( k >= 0 && k == k_was + 1 );
+			const int	n_f = rmd_imin( __popcll( idle ), __popcll( down ) );
+			if( n_f > 0 ){
+				const bool	taker = k < 0 && dry && __popcll( idle & lt_mask ) < n_f;
+				const bool	giver = k >= 0 && k == k_was + 1 && __popcll( down & lt_mask ) < n_f;
+				int	src = lane_id;
+				if( taker ){
+					unsigned long long	m = down;
+					for( int q = __popcll( idle & lt_mask ); q > 0; q-- )
+						m &= m - 1;
+					src = __ffsll( m ) - 1;
+				}
+				// (every lane takes part in the exchanges; a lane that is not a taker reads its own values)
+				const int	k_src = __shfl( k, src );
+				st.szero = __shfl( st.szero, src );
+				st.slen = __shfl( st.slen, src );
+				st.hi0 = __shfl( st.hi0, src );
+				st.lo0 = __shfl( st.lo0, src );
+				st.rank = __shfl( st.rank, src );
+				st.order = __shfl( st.order, src );
+				st.pretested = __shfl( st.pretested, src );
+				st.hm_level = __shfl( st.hm_level, src );
+				st.hmask[ 0 ] = __shfl( st.hmask[ 0 ], src );
+				st.hmask[ 1 ] = __shfl( st.hmask[ 1 ], src );
+				st.only_hl = __shfl( st.only_hl, src );
+				nsq.flip = __shfl( nsq.flip, src );
+				nsq.bias = __shfl( nsq.bias, src );
+				sink.seq = __shfl( sink.seq, src );
+				sink.comp = __shfl( sink.comp, src );
+				obase = __shfl( obase, src );
+				if( taker ){
+					const uint32_t	*lo_s = lr.lo + ( src - lane_id );
+					const uint16_t	*hi_s = lr.hi + ( src - lane_id );
+					for( int j = 0; j < P->n_searches; j++ ){
+						lr.lo[ j * BLOCK ] = lo_s[ j * BLOCK ];
+						lr.hi[ j * BLOCK ] = hi_s[ j * BLOCK ];
+					}
+					const uint32_t	*col_s = col + ( src - lane_id );
+					for( int j = 0; j < DRAIN_NIB; j++ )
+						col[ j * BLOCK ] = col_s[ j * BLOCK ];
+					st.pending = 0;
+					k = k_src;
+					floor_ = k_src;
+					t_item = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
+					n_steps = n_emit = 0;
+				}
+				if( giver )
+					k = k_was;	// (back at its own level, the subtree below as good as walked)
+			}
+		}
 		if( ( dbg & 32 ) && was && k < 0 ){
 			// (diagnostic: how long the items take, how many steps, how many complete matches)
 			const unsigned long long	dt = __builtin_amdgcn_s_memtime() - t_item;

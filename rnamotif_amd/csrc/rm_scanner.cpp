@@ -1322,7 +1322,9 @@ static int scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, b
 		return 0;
 	}
 	if( n == 1 && !sc->opt.host_sort ){
-		// (a single record is in order)
+		// (a single record is in order; its order word -- the kernels leave the number of the walk's choices
+		// there, or a count within a piece of an item -- is 0 as the sorts would make it)
+		HIPCHK( hipMemsetAsync( sc->d_hits + 4, 0, sizeof( int32_t ), sc->stream ) );
 		if( copy_back )
 			HIPCHK( hipMemcpyAsync( sc->h_raw, sc->d_hits, words * sizeof( int32_t ), hipMemcpyDeviceToHost, sc->stream ) );
 		HIPCHK( hipStreamSynchronize( sc->stream ) );
