@@ -88,7 +88,7 @@ def synthetic_slice(first: int, count: int, length: int):
     return out
 
 
-def profile_counters(kernel="rma_search_kernel"):
+def profile_counters(kernels=("rma_search_kernel", "rma_drain_kernel")):
     """Per-launch means of the committed PMC passes over the default workload -- or None when the
     summary was made from other kernel sources than the ones this run uses."""
     import csv
@@ -97,10 +97,11 @@ def profile_counters(kernel="rma_search_kernel"):
         return None
     if json.load(open(meta)).get("kernel_hash") != kernel_hash():
         return None
+    # (one launch of each per scan: the search kernel and the drain kernel that walks what it left in its list)
     c = {}
     for r in csv.DictReader(open(summ)):
-        if kernel in r["kernel"]:
-            c[r["counter"]] = float(r["mean_per_dispatch"])
+        if any(k in r["kernel"] for k in kernels):
+            c[r["counter"]] = c.get(r["counter"], 0.0) + float(r["mean_per_dispatch"])
     return c or None
 
 
@@ -394,19 +395,29 @@ def main():
         job_bases = db.bases
 
     # kernel time of the dominant kernel, HIP events on the scanner's own stream; then the pre-filter alone
-    def kernel_ms(reps=5):
+    parts = {"rma_search_kernel": [], "rma_drain_kernel": []}
+
+    def kernel_ms(reps=5, keep_parts=False):
         s_tot, e_tot = [], []
         for _ in range(reps):
             tot = [0.0, 0.0]
+            p0 = p1 = 0.0
             for sc_ in scs:
                 _, s_ms, e_ms = sc_.scan_device(db)
                 tot[0] += s_ms
                 tot[1] += e_ms
+                k_ms = sc_.last_kernel_ms()
+                p0 += k_ms[0]
+                p1 += k_ms[1]
             s_tot.append(tot[0])
             e_tot.append(tot[1])
+            if keep_parts:
+                parts["rma_search_kernel"].append(p0)
+                parts["rma_drain_kernel"].append(p1)
         return float(np.mean(s_tot)), float(np.mean(e_tot))
 
-    search_ms, efn_ms = kernel_ms()
+    search_ms, efn_ms = kernel_ms(keep_parts=True)
+    drain_ms = float(np.mean(parts["rma_drain_kernel"]))
     pass_a_ms = None
     if rank == 0 and world == 1 and args.cpu_bases > 0:       # (not under the profiler: profiles/collect.sh passes --cpu-bases 0,
         # so that every launch of the kernel it counts is a whole one)
@@ -483,7 +494,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "rma_search_kernel",
+                "kernel": "rma_search_kernel + rma_drain_kernel" if drain_ms > 0 else "rma_search_kernel",
+                "kernel_parts_ms": {k: round(float(np.mean(v)), 3) for k, v in parts.items()},
                 "achieved": round(achieved, 4),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -499,7 +511,9 @@ def main():
                 "efn_kernel_ms": round(efn_ms, 3),
                 "kernel_hash": kernel_hash(),
                 "secondary": secondary,
-                "note": "the search is integer/LDS work with dependent accesses, not HBM bound (SURVEY.md 8d); pass A = "
+                "note": "the search is integer/LDS work with dependent accesses, not HBM bound (SURVEY.md 8d); kernel_ms = the search "
+                        "kernel and, where the descriptor has one, the drain kernel launched behind it (the walks of the items the "
+                        "search kernel's filters let through), HIP events on the scanner's stream; pass A = "
                         "pre-filter (decode, bit rows, first-pairs test, queue), pass B = the search proper; "
                         "kernel-only rate = %.1f Mbases/s" % (bases_per_gpu * len(descrs) / (search_ms * 1e-3) / 1e6),
             },

@@ -173,6 +173,10 @@ int	rma_scan_end_on_device( rma_scanner_t *sc, const int32_t **d_hits, int64_t *
  * search kernel as measured with HIP events on the scanner's stream. */
 int	rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *n_hits, float *search_ms,
 		float *efn_ms, char *err, size_t errlen );
+/* The kernels of the scanner's last search (HIP events on its stream): ms[0] the search kernel, ms[1] the
+ * drain kernel that walked the items the search kernel left in its list (0: the search kernel walked
+ * them itself), ms[2] the efn kernel (0: none).  search_ms above is ms[0] + ms[1]. */
+int	rma_scanner_last_kernel_ms( rma_scanner_t *sc, float ms[ 3 ], char *err, size_t errlen );
 
 /* Records from several scans (the slices of one database searched by several GPUs or hosts, word 0
  * already the database-wide entry number) into the reference's output order: by the five header

@@ -106,6 +106,7 @@ def lib() -> C.CDLL:
     L.rma_db_bases.argtypes = [vp]
     L.rma_db_bases.restype = C.c_int64
     L.rma_scan.argtypes = [vp, vp, C.POINTER(i32p), i64p, C.c_char_p, C.c_size_t]
+    L.rma_scanner_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_char_p, C.c_size_t]
     L.rma_scan_device.argtypes = [vp, vp, i64p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                   C.c_char_p, C.c_size_t]
     L.rma_replay_open.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -315,6 +316,13 @@ class Scanner:
         err = C.create_string_buffer(_ERRLEN)
         _check(L.rma_scan_device(self._h, db._h, C.byref(n), C.byref(ms1), C.byref(ms2), err, _ERRLEN), err)
         return n.value, ms1.value, ms2.value
+
+    def last_kernel_ms(self) -> Tuple[float, float, float]:
+        """(search kernel, drain kernel, efn kernel) of the last search in ms; 0 for a kernel that did not run."""
+        ms = (C.c_float * 3)()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_scanner_last_kernel_ms(self._h, ms, err, _ERRLEN), err)
+        return ms[0], ms[1], ms[2]
 
     def close(self) -> None:
         if self._h:

@@ -248,7 +248,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		}
 	}
 	// (window below 4096: the lean records pack positions into 12 bits, rm_scan_hip.hip)
-	out->lean_ok = p->n_searches <= RMD_LEAN_LEVELS && out->w_winsize < 4096;
+	out->lean_ok = p->n_searches <= RMD_LEAN_LEVELS && out->w_winsize < 4096 && p->n_elems <= 64;	// (64: an element per lane, the kernel's WaveTable)
 	for( int s = 0; s < p->n_searches; s++ ){
 		const rma_elem_t	&e = p->elems[ p->searches[ s ] ];
 		if( !( e.type == RMA_T_SS || ( e.type == RMA_T_H5 && e.proper ) ) )

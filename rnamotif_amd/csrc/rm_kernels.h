@@ -68,7 +68,7 @@ struct HitBuf {
 #define RMK_N_COUNTERS		128	// 64-bit counters behind a launch: [0] candidates, [1] ticket, diagnostics, [RMK_GCTL] the list's two
 #define RMK_GCTL		100
 #define PIECE_ORDER_BITS	12	// candidates a piece of an item may find; more, and the search is repeated with whole items (ticket[ 2 ])
-#define GLIST_FLUSH		32	// items a workgroup's pool holds when it is flushed to the list (and whatever it holds at the end)
+#define GLIST_BELOW		128	// what a workgroup's pool holds at the end goes to the list when it is less than this
 #define SEARCH_BLOCK		256	// lanes of a search workgroup of the lean instances
 // ... and of the general instances: ONE wave.  The waves of a four-wave workgroup met at the end of
 // every tile, and the tile's second round -- a few dozen continuations, each a long walk -- kept one of
@@ -105,7 +105,7 @@ struct rmk_search_args {
 hipError_t	rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 // the launchers behind it, one translation unit each (rm_scan_inst_*.hip)
 hipError_t	rmk_launch_lean_pool( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
-hipError_t	rmk_launch_lean_drain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );	// (qcap, tile_bytes: not used)
+hipError_t	rmk_launch_lean_drain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );	// (qcap: not used; tile_bytes: window dwords per lane)
 hipError_t	rmk_launch_lean_group( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_tile( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_plain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );

@@ -94,30 +94,22 @@ struct LdsRecs {
 // chk_motif's fm_window lookups walk it element by element, four times per strict helix; the other lanes
 // of the wave wait meanwhile, and an item with twenty alternatives holds its wave for milliseconds
 // (RNAMOTIF_DBG=34: 38 % of pass B's wave cycles over trna.descr, and all of its tail).  Here the
-// wave does it together: lane j rebuilds search levels j and j + 64 from the records of the lane that
-// found the match, lane e keeps elements e and e + 64 of the table in registers, a window lookup is a
+// wave does it together: lane j rebuilds search level j from the records of the lane that
+// found the match (levels j and up to 16), lane e keeps element e of the table in registers, a window lookup is a
 // ballot, the candidate's words go out side by side.  No scratch memory, a few thousand cycles.
 struct WaveTable {
-	int	moff[ 2 ], mlen[ 2 ], type[ 2 ], mpr[ 2 ], mm[ 2 ];	// of elements lane and lane + 64
+	int	moff, mlen, type, mpr, mm;		// of element `lane` (lean descriptors have at most 32)
 	int	l_off, l_len, r_off, r_len, l_mm, r_mm;		// (the same in every lane)
 	int	slen;
-	// (d is the same in every lane wherever the checks call these)
-	__device__ inline int	off( int d ) const
-	{
-		const int	a = __shfl( moff[ 0 ], d & 63 ), b = __shfl( moff[ 1 ], d & 63 );
-		return d < 64 ? a : b;
-	}
-	__device__ inline int	len( int d ) const
-	{
-		const int	a = __shfl( mlen[ 0 ], d & 63 ), b = __shfl( mlen[ 1 ], d & 63 );
-		return d < 64 ? a : b;
-	}
+	// (d is the same in every lane wherever the checks call these: a scalar read of lane d's register)
+	__device__ inline int	off( int d ) const { return __builtin_amdgcn_readlane( moff, __builtin_amdgcn_readfirstlane( d ) ); }
+	__device__ inline int	len( int d ) const { return __builtin_amdgcn_readlane( mlen, __builtin_amdgcn_readfirstlane( d ) ); }
 	__device__ inline int	wtype( const rmd_program_t *, int pos, int undef_is_ss ) const	// rmd_lane_t::wtype: the first element that covers pos
 	{
-		const unsigned long long	b0 = __ballot( mlen[ 0 ] > 0 && pos >= moff[ 0 ] && pos < moff[ 0 ] + mlen[ 0 ] );
-		const unsigned long long	b1 = __ballot( mlen[ 1 ] > 0 && pos >= moff[ 1 ] && pos < moff[ 1 ] + mlen[ 1 ] );
-		const int	t0 = __shfl( type[ 0 ], b0 ? __ffsll( b0 ) - 1 : 0 ), t1 = __shfl( type[ 1 ], b1 ? __ffsll( b1 ) - 1 : 0 );
-		return b0 ? t0 : b1 ? t1 : undef_is_ss ? RMA_T_SS : -1;
+		const unsigned long long	b = __ballot( mlen > 0 && pos >= moff && pos < moff + mlen );
+		if( b == 0 )
+			return undef_is_ss ? RMA_T_SS : -1;
+		return __builtin_amdgcn_readlane( type, __builtin_amdgcn_readfirstlane( __ffsll( b ) - 1 ) );
 	}
 };
 
@@ -125,61 +117,56 @@ struct WaveTable {
 // state of the lane whose search reached the end of the list.  True when the candidate passed the checks
 // (and was stored, room permitting): the caller counts that lane's `order` up.
 template< int BLOCK, class LR, class SQ >
-__device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, const SQ sq, int z, int slen, int rank, int order,
+__device__ __forceinline__ bool wave_emit_body( const rmd_program_t *P, const LR lr, const SQ sq, int z, int slen, int rank, int order,
 	int seq, int comp, int32_t *hits, unsigned long long *count, long long cap, int lane_id )
 {
-	// lane j: levels j and j + 64, as rmd_lean_emit's loop has them
-	int	lz[ 2 ] = { 0, 0 }, lc[ 2 ] = { 0, 0 }, lx[ 2 ] = { 0, 0 }, lm[ 2 ] = { 0, 0 };
-	int	digits = 0;	// (the levels' share of the order word, rmd_elem_t::ord_stride)
-#pragma unroll
-	for( int s = 0; s < 2; s++ ){
-		const int	kk = lane_id + 64 * s;
-		if( kk < P->n_searches ){
-			const rmd_lrec_t	r = lr.get( kk );
-			const int	d = P->searches[ kk ];
-			const rmd_elem_t	&stp = P->elems[ d ];
-			const int	zero = z + r.zero, cur = z + r.sd + 1;
-			lz[ s ] = zero;
-			lc[ s ] = cur;
-			{
-				const int	first = ( kk == 0 || !stp.loop ) ? int( r.sd ) + 1 : int( rmd_lean_open( P, kk, r.zero, r.osd ).sd );
-				digits += ( ( first - ( int( r.sd ) + 1 ) ) * stp.ord_nlen + ( stp.type == RMA_T_SS ? 0 : int( r.hl ) - stp.minlen ) ) * stp.ord_stride;
-			}
-			if( stp.type == RMA_T_SS ){
-				int	mm = 0;
-				if( stp.re >= 0 && stp.mismatch > 0 )
-					rmd_chk_seq( P, stp, sq, zero, cur - zero + 1, &mm );
-				lm[ s ] = mm & 0xffff;
-			}else{
-				const int	hl = r.hl;
-				uint64_t	cand, mis;
-				int	mm5 = 0, mm3 = 0;
-				rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], zero, cur, rmd_s3lim( zero, cur, stp.minilen, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
-				lx[ s ] = hl | ( rmd_popc64( mis & ( ( 1ull << hl ) - 1 ) ) << 8 );
-				lm[ s ] = ( mm5 & 0xffff ) | ( mm3 << 16 );
-			}
+	// lane j: level j, as rmd_lean_emit's loop has it
+	int	lz = 0, lc = 0, lx = 0, lm = 0;
+	int	digits = 0;	// (the level's share of the order word, rmd_elem_t::ord_stride)
+	if( lane_id < P->n_searches ){
+		const int	kk = lane_id;
+		const rmd_lrec_t	r = lr.get( kk );
+		const int	d = P->searches[ kk ];
+		const rmd_elem_t	&stp = P->elems[ d ];
+		const int	zero = z + r.zero, cur = z + r.sd + 1;
+		lz = zero;
+		lc = cur;
+		{
+			const int	first = ( kk == 0 || !stp.loop ) ? int( r.sd ) + 1 : int( rmd_lean_open( P, kk, r.zero, r.osd ).sd );
+			digits = ( ( first - ( int( r.sd ) + 1 ) ) * stp.ord_nlen + ( stp.type == RMA_T_SS ? 0 : int( r.hl ) - stp.minlen ) ) * stp.ord_stride;
+		}
+		if( stp.type == RMA_T_SS ){
+			int	mm = 0;
+			if( stp.re >= 0 && stp.mismatch > 0 )
+				rmd_chk_seq( P, stp, sq, zero, cur - zero + 1, &mm );
+			lm = mm & 0xffff;
+		}else{
+			const int	hl = r.hl;
+			uint64_t	cand, mis;
+			int	mm5 = 0, mm3 = 0;
+			rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], zero, cur, rmd_s3lim( zero, cur, stp.minilen, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
+			lx = hl | ( rmd_popc64( mis & ( ( 1ull << hl ) - 1 ) ) << 8 );
+			lm = ( mm5 & 0xffff ) | ( mm3 << 16 );
 		}
 	}
-	// lane e: elements e and e + 64, each from the level that placed it (a 3' strand: its helix's)
+	// lane e: element e, from the level that placed it (a 3' strand: its helix's)
 	WaveTable	tb;
-#pragma unroll
-	for( int s = 0; s < 2; s++ ){
-		const int	e = lane_id + 64 * s;
+	{
+		const int	e = lane_id;
 		const bool	in = e < P->n_elems;
 		const rmd_elem_t	&el = P->elems[ in ? e : 0 ];
 		const int	ty = el.type;
 		const int	lv_ = ty == RMA_T_H3 ? P->elems[ el.mates[ 0 ] ].searchno : el.searchno;
 		const bool	placed = in && lv_ >= 0;
-		const int	lv = placed ? lv_ : 0, src = lv & 63;
-		const int	z0 = __shfl( lz[ 0 ], src ), z1 = __shfl( lz[ 1 ], src ), c0 = __shfl( lc[ 0 ], src ), c1 = __shfl( lc[ 1 ], src );
-		const int	x0 = __shfl( lx[ 0 ], src ), x1 = __shfl( lx[ 1 ], src ), m0 = __shfl( lm[ 0 ], src ), m1 = __shfl( lm[ 1 ], src );
-		const int	zero = lv < 64 ? z0 : z1, cur = lv < 64 ? c0 : c1, x = lv < 64 ? x0 : x1, m = lv < 64 ? m0 : m1;
+		const int	src = placed ? lv_ : 0;
+		// (every lane takes part in the exchanges)
+		const int	zero = __shfl( lz, src ), cur = __shfl( lc, src ), x = __shfl( lx, src ), m = __shfl( lm, src );
 		const int	hl = x & 0xff;
-		tb.type[ s ] = in ? ty : -1;
-		tb.moff[ s ] = !placed ? 0 : ty == RMA_T_H3 ? cur - hl + 1 : zero;
-		tb.mlen[ s ] = !placed ? 0 : ty == RMA_T_SS ? cur - zero + 1 : hl;
-		tb.mpr[ s ] = !placed || ty == RMA_T_SS ? 0 : x >> 8;
-		tb.mm[ s ] = !placed ? 0 : ty == RMA_T_H3 ? ( m >> 16 ) : int( int16_t( m & 0xffff ) );
+		tb.type = in ? ty : -1;
+		tb.moff = !placed ? 0 : ty == RMA_T_H3 ? cur - hl + 1 : zero;
+		tb.mlen = !placed ? 0 : ty == RMA_T_SS ? cur - zero + 1 : hl;
+		tb.mpr = !placed || ty == RMA_T_SS ? 0 : x >> 8;
+		tb.mm = !placed ? 0 : ty == RMA_T_H3 ? ( m >> 16 ) : int( int16_t( m & 0xffff ) );
 	}
 	if( P->ord_ok ){
 		for( int o = 32; o > 0; o >>= 1 )
@@ -213,15 +200,11 @@ __device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, con
 			w[ k + 2 ] = P->has_rctx ? tb.r_off : 0;
 			w[ k + 3 ] = P->has_rctx ? tb.r_len : 0;
 		}
-#pragma unroll
-		for( int s = 0; s < 2; s++ ){
-			const int	e = lane_id + 64 * s;
-			if( e < P->n_elems ){
-				w[ RMA_HIT_HDR + 4 * e + 0 ] = tb.moff[ s ];
-				w[ RMA_HIT_HDR + 4 * e + 1 ] = tb.mlen[ s ];
-				w[ RMA_HIT_HDR + 4 * e + 2 ] = tb.mpr[ s ];
-				w[ RMA_HIT_HDR + 4 * e + 3 ] = tb.mm[ s ];
-			}
+		if( lane_id < P->n_elems ){
+			w[ RMA_HIT_HDR + 4 * lane_id + 0 ] = tb.moff;
+			w[ RMA_HIT_HDR + 4 * lane_id + 1 ] = tb.mlen;
+			w[ RMA_HIT_HDR + 4 * lane_id + 2 ] = tb.mpr;
+			w[ RMA_HIT_HDR + 4 * lane_id + 3 ] = tb.mm;
 		}
 		for( int e = lane_id; e < P->n_efn; e += 64 )
 			w[ k + 4 + e ] = RMA_EFN_INFINITY;	// filled by the efn pass
@@ -229,9 +212,17 @@ __device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, con
 	return true;
 }
 
+// (out of line where complete matches are rare -- the search kernel's own walks; in line in the drain kernel)
+template< int BLOCK, class LR, class SQ >
+__device__ __noinline__ bool wave_emit( const rmd_program_t *P, const LR lr, const SQ sq, int z, int slen, int rank, int order,
+	int seq, int comp, int32_t *hits, unsigned long long *count, long long cap, int lane_id )
+{
+	return wave_emit_body<BLOCK>( P, lr, sq, z, slen, rank, order, seq, comp, hits, count, cap, lane_id );
+}
+
 // The matches the lanes of a wave have pending after a step (rmd_lean_t::pending), one at a time;
 // sq_of( l ): the sequence view lane l searches in.  Called by all 64 lanes.
-template< int BLOCK, class SQOF >
+template< int BLOCK, bool INLINE = false, class SQOF >
 __device__ inline void wave_emit_pending( const rmd_program_t *P, const LdsRecs<BLOCK> &lr, rmd_lean_t &st, int k, const SQOF &sq_of,
 	int seq, int comp, const HitBuf &hb, int lane_id, int order_base = 0 )
 {
@@ -240,8 +231,13 @@ __device__ inline void wave_emit_pending( const rmd_program_t *P, const LdsRecs<
 		const LdsRecs<BLOCK>	lrl{ lr.lo + ( l - lane_id ), lr.hi + ( l - lane_id ) };
 		if( lane_id == l && st.only_hl >= 0 && st.order >= ( 1 << PIECE_ORDER_BITS ) )
 			atomicMax( hb.ticket + 2, 1ull );	// (the pieces' order words would run into each other)
-		const bool	stored = wave_emit<BLOCK>( P, lrl, sq_of( l ), __shfl( st.szero, l ), __shfl( st.slen, l ), __shfl( st.rank, l ),
-			__shfl( st.order + order_base, l ), __shfl( seq, l ), __shfl( comp, l ), hb.hits, hb.count, hb.cap, lane_id );
+		bool	stored;
+		if constexpr( INLINE )
+			stored = wave_emit_body<BLOCK>( P, lrl, sq_of( l ), __shfl( st.szero, l ), __shfl( st.slen, l ), __shfl( st.rank, l ),
+				__shfl( st.order + order_base, l ), __shfl( seq, l ), __shfl( comp, l ), hb.hits, hb.count, hb.cap, lane_id );
+		else
+			stored = wave_emit<BLOCK>( P, lrl, sq_of( l ), __shfl( st.szero, l ), __shfl( st.slen, l ), __shfl( st.rank, l ),
+				__shfl( st.order + order_base, l ), __shfl( seq, l ), __shfl( comp, l ), hb.hits, hb.count, hb.cap, lane_id );
 		if( lane_id == l ){
 			st.order += stored;
 			st.pending = 0;
@@ -699,10 +695,9 @@ __device__ inline void pool_sub_piece( unsigned rc, unsigned h0, unsigned h1, in
 // (RNAMOTIF_DBG bit 1048576).  This kernel comes after it on the same stream: workgroups of ONE wave (no
 // barrier anywhere), every wave taking its fair share of the list, then more as lanes come free.
 #define DRAIN_BLOCK	64
-#define DRAIN_NIB	32	// window dwords per lane (the host has checked the descriptor's window against it)
 template< int BLOCK >
 __global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
-rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb, int dbg )
+rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb, int n_nib, int dbg )
 {
 	static_assert( BLOCK == 64, "one wave per workgroup" );
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
@@ -712,7 +707,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 		reinterpret_cast<uint32_t *>( P )[ i ] = reinterpret_cast<const uint32_t *>( gP )[ i ];
 	__syncthreads();
 	uint32_t	*const col = reinterpret_cast<uint32_t *>( smem + prog_bytes ) + tid;
-	uint32_t	*const lean_lo = reinterpret_cast<uint32_t *>( smem + prog_bytes ) + DRAIN_NIB * BLOCK;
+	uint32_t	*const lean_lo = reinterpret_cast<uint32_t *>( smem + prog_bytes ) + n_nib * BLOCK;	// (n_nib: window dwords per lane)
 	uint16_t	*const lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
 	LdsRecs<BLOCK>	lr{ lean_lo + tid, lean_hi + tid };
 	const unsigned long long	lt_mask = ( 1ull << lane_id ) - 1;
@@ -747,7 +742,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 					const unsigned	*e = hb.pool + RMK_POOL_WORDS * size_t( i );
 					// (a workgroup whose items found no room in the list left its share of it void)
 					if( __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) != 0xffffffffu ){
-						k = pool_item_begin<BLOCK>( P, db, e, col, DRAIN_NIB, lr, st, nsq, sink.seq, sink.comp, obase );
+						k = pool_item_begin<BLOCK>( P, db, e, col, n_nib, lr, st, nsq, sink.seq, sink.comp, obase );
 						floor_ = 0;
 						t_item = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
 						n_steps = n_emit = 0;
@@ -766,7 +761,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 			n_steps++;
 			n_emit += st.pending;
 		}
-		wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int l ){
+		wave_emit_pending<BLOCK, true>( P, lr, st, k, [ & ]( int l ){
 			return rmd_nibseq_t<BLOCK>{ nsq.w + ( l - lane_id ), __shfl( nsq.flip, l ), __shfl( nsq.bias, l ) }; },
 			sink.seq, sink.comp, hb, lane_id, obase );
 		if( k >= 0 && k < floor_ )
@@ -816,7 +811,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 						lr.hi[ j * BLOCK ] = hi_s[ j * BLOCK ];
 					}
 					const uint32_t	*col_s = col + ( src - lane_id );
-					for( int j = 0; j < DRAIN_NIB; j++ )
+					for( int j = 0; j < n_nib; j++ )
 						col[ j * BLOCK ] = col_s[ j * BLOCK ];
 					st.pending = 0;
 					k = k_src;
@@ -1779,9 +1774,12 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			}
 			PHASE( 3 );
 			__syncthreads();
-			// the workgroup's pool goes to the device-wide list the drain kernel works on (rma_drain_kernel), now and
-			// then and at the end; only when that list is full the workgroup walks its items itself, as below
-			if( hb.glist_cap > 0 && s_glist_full == 0 && s_pool_n > 0 && ( last || s_pool_n >= GLIST_FLUSH ) ){
+			// What the workgroup's pool still holds at the end goes to the device-wide list the drain kernel works on
+			// (rma_drain_kernel) when it is too little to keep the workgroup's lanes busy: GLIST_BELOW items.  (Many
+			// items, as ire.descr and mp.ends.descr leave them -- some hundred per workgroup, a step or two each --
+			// are walked best where they are, 256 lanes on them while other workgroups still filter: 0.05 ms against
+			// 0.28 in the drain kernel.  trna.descr leaves some twenty per workgroup, walks of dozens of steps.)
+			if( hb.glist_cap > 0 && s_glist_full == 0 && s_pool_n > 0 && last && ( s_pool_n < GLIST_BELOW || ( dbg & 8388608 ) ) && !( dbg & 2048 ) ){
 				const int	n_fl = s_pool_n;
 				const bool	cut = !( dbg & 2097152 );		// (diagnostic: items go whole)
 				// how many list items the pool's make (pool_sub_count) ...
@@ -2096,6 +2094,6 @@ hipError_t name_( int grid, size_t lds, hipStream_t s, const rmk_search_args &a 
 	hipError_t	e = hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ); \
 	if( e != hipSuccess ) \
 		return e; \
-	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( DRAIN_BLOCK ), lds, s, a.d_prog, a.prog_bytes, a.db, a.hb, a.dbg ); \
+	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( DRAIN_BLOCK ), lds, s, a.d_prog, a.prog_bytes, a.db, a.hb, a.tile_bytes, a.dbg ); \
 	return hipGetLastError(); \
 }

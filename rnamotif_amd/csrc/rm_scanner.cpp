@@ -189,7 +189,8 @@ struct rma_scanner {
 	int	device = 0;
 	DevCtx	*ctx = nullptr;
 	hipStream_t	stream = nullptr;
-	hipEvent_t	ev[ 4 ] = { nullptr, nullptr, nullptr, nullptr };
+	hipEvent_t	ev[ 5 ] = { nullptr, nullptr, nullptr, nullptr, nullptr };	// search kernel's start / end, efn kernel's, [4]: the search kernel's end when a drain kernel follows
+	bool	drained = false;		// the last launch had a drain kernel
 	rma_efn2data_t	*d_efn2 = nullptr;	// efn2() tables, global memory
 	bool	need_efn2 = false;
 	rmd_program_t	*d_prog = nullptr;	// compact image, prog_bytes long
@@ -214,7 +215,7 @@ struct rma_scanner {
 	rma::DevHitSort	dsort;		// ordering on the device (rm_hitsort_dev.h)
 	unsigned long long	*h_ctr = nullptr;	// pinned: the counters a launch leaves
 	int	tile_t = 2048;
-	int	drain_grid = 0;
+	int	drain_grid = 0, drain_nib = 0;
 	size_t	drain_lds = 0;
 	int	grid_blocks = 0;		// most workgroups of a launch of a lean instance (eight of four waves per CU)
 	int	spill_blocks = 0;		// workgroups d_spill has areas for
@@ -375,7 +376,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	if( sc->ctx == nullptr )
 		return 1;
 	HIPCHK( hipStreamCreateWithFlags( &sc->stream, hipStreamNonBlocking ) );
-	for( int i = 0; i < 4; i++ )
+	for( int i = 0; i < 5; i++ )
 		HIPCHK( hipEventCreate( &sc->ev[ i ] ) );
 	{
 		// the device gets the compact image; sc->dprog stays the full struct for the host
@@ -566,7 +567,7 @@ extern "C" void rma_scanner_destroy( rma_scanner_t *sc )
 	( void )hipFree( sc->d_counters );
 	( void )hipFree( sc->d_spill );
 	( void )hipFree( sc->d_pool );
-	for( int i = 0; i < 4; i++ )
+	for( int i = 0; i < 5; i++ )
 		if( sc->ev[ i ] )
 			( void )hipEventDestroy( sc->ev[ i ] );
 	if( sc->stream )
@@ -960,8 +961,12 @@ static int launch_search( rma_scanner_t *sc, char *err, size_t errlen )
 	a.dbg = sc->opt.dbg | ( sc->whole_items ? 2097152 : 0 );
 	HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 	HIPCHK( rmk_launch_search( f.inst, f.grid, f.lds, sc->stream, a ) );
-	if( drain )	// the items the search kernel left in the list: walked by a kernel of their own
+	sc->drained = drain;
+	if( drain ){	// the items the search kernel left in the list: walked by a kernel of their own
+		HIPCHK( hipEventRecord( sc->ev[ 4 ], sc->stream ) );
+		a.tile_bytes = sc->drain_nib;
 		HIPCHK( rmk_launch_lean_drain( sc->drain_grid, sc->drain_lds, sc->stream, a ) );
+	}
 	HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
 	// [0] candidates, [3] queue overflow of the general instance: one copy, one wait
 	HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->d_counters, 4 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, sc->stream ) );
@@ -1111,7 +1116,8 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 			sc->glist_cap = want;
 		}
 		// the drain kernel: one wave per workgroup -- the program, a window column and the records of 64 lanes
-		sc->drain_lds = size_t( sc->prog_bytes ) + size_t( 32 + dp.n_searches ) * 64 * sizeof( uint32_t ) + size_t( dp.n_searches ) * 64 * sizeof( uint16_t );
+		sc->drain_nib = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;	// (n_dw above: at most 32)
+		sc->drain_lds = size_t( sc->prog_bytes ) + size_t( sc->drain_nib + dp.n_searches ) * 64 * sizeof( uint32_t ) + size_t( dp.n_searches ) * 64 * sizeof( uint16_t );
 		const int	per_cu = int( std::min<size_t>( 4 * SEARCH_WAVES_PER_SIMD, ( 160 * 1024 ) / ( sc->drain_lds + 64 ) ) );
 		sc->drain_grid = ( sc->grid_blocks / 8 ) * std::max( 1, per_cu );
 	}
@@ -1239,6 +1245,28 @@ extern "C" int rma_scan_device( rma_scanner_t *sc, const rma_db_t *db, int64_t *
 	HIPCHK( hipStreamSynchronize( sc->stream ) );
 	if( efn_ms && has_efn )
 		HIPCHK( hipEventElapsedTime( efn_ms, sc->ev[ 2 ], sc->ev[ 3 ] ) );
+	return 0;
+}
+
+// The kernels of the scanner's last search, by HIP events on its stream: ms[ 0 ] the search kernel, ms[ 1 ] the
+// drain kernel that walked what it left in the list (0: there was none), ms[ 2 ] the efn kernel (0: none).
+extern "C" int rma_scanner_last_kernel_ms( rma_scanner_t *sc, float ms[ 3 ], char *err, size_t errlen )
+{
+	HIPCHK( hipSetDevice( sc->device ) );
+	ms[ 0 ] = ms[ 1 ] = ms[ 2 ] = 0;
+	HIPCHK( hipStreamSynchronize( sc->stream ) );
+	if( hipEventQuery( sc->ev[ 1 ] ) != hipSuccess )
+		return 0;		// (nothing was launched yet)
+	if( sc->drained ){
+		HIPCHK( hipEventElapsedTime( &ms[ 0 ], sc->ev[ 0 ], sc->ev[ 4 ] ) );
+		HIPCHK( hipEventElapsedTime( &ms[ 1 ], sc->ev[ 4 ], sc->ev[ 1 ] ) );
+	}else
+		HIPCHK( hipEventElapsedTime( &ms[ 0 ], sc->ev[ 0 ], sc->ev[ 1 ] ) );
+	if( hipEventQuery( sc->ev[ 3 ] ) == hipSuccess && hipEventQuery( sc->ev[ 2 ] ) == hipSuccess ){
+		float	e = 0;
+		if( hipEventElapsedTime( &e, sc->ev[ 2 ], sc->ev[ 3 ] ) == hipSuccess && e >= 0 )
+			ms[ 2 ] = e;
+	}
 	return 0;
 }
 
