@@ -206,8 +206,11 @@ def test_pooled_and_tile_by_tile_pass_b_agree(built, workdir, gbrna, name):
     want = oracle_scan(d, seqs)
     sc = R.Scanner(d)
     db = sc.database(seqs)
-    base = {"pool": -1, "pool_min": 1024, "pool_refill": 48}
-    for opts in ({}, {"pool": 0}, {"pool_min": 8, "pool_refill": 1}, {"pool_min": 100000}):
+    # drain 0: every workgroup walks its own items; dbg 2097152: the drain kernel's items stay whole (no pieces);
+    # 4194304: no subtrees handed to idle lanes; 8388608: everything a workgroup holds at the end goes to the list
+    base = {"pool": -1, "pool_min": 1024, "pool_refill": 48, "drain": 1, "dbg": 0}
+    for opts in ({}, {"pool": 0}, {"pool_min": 8, "pool_refill": 1}, {"pool_min": 100000}, {"drain": 0}, {"dbg": 2097152},
+                 {"dbg": 4194304}, {"dbg": 8388608}, {"dbg": 8388608 + 4194304 + 2097152}, {"dbg": 8388608, "pool_refill": 1}):
         for k, v in dict(base, **opts).items():
             sc.set_option(k, v)
         got = sc.scan(db)
@@ -906,6 +909,43 @@ def test_random_descriptors_under_stress_settings(built, tmp_path, seed, gen):
                 os.environ[k] = v
     assert got.shape == want.shape, text
     assert np.array_equal(got, want), text
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_lean_descriptors_through_the_drain_kernel(built, tmp_path, seed):
+    """Generated ss / helix descriptors over planted sequence with everything the search kernel's filters let
+    through walked by the drain kernel (dbg 8388608) -- in pieces and whole, with and without subtrees handed
+    to idle lanes -- and by the workgroups themselves (drain 0): the same records, bit for bit, as the oracle's.
+    (The order words of the candidates are numbers of the walk's choices there, counts here: both sorts
+    renumber them.)"""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(7000 + seed)
+    text = _random_descriptor(rng)
+    path = tmp_path / "rand.descr"
+    path.write_text(text)
+    try:
+        d = R.Descriptor(["-descr", str(path)])
+    except R.RnamotifError:
+        pytest.skip("generated descriptor does not compile")
+    if d.maxlen > 200:
+        pytest.skip("window too large for a quick differential run")
+    s = _planted_sequence(rng, 20_000)
+    seqs = [s, b"", s[:d.minlen], s[:d.maxlen + 1], s[100:100 + 2047], _planted_sequence(rng, 3_000)]
+    want = oracle_scan(d, seqs)
+    if want.shape[0] > 300_000:
+        pytest.skip("too many candidates for a quick run")
+    try:
+        sc = R.Scanner(d)
+    except R.RnamotifError as e:
+        pytest.skip("refused by the device build: " + str(e))
+    db = sc.database(seqs)
+    for opts in ({"dbg": 8388608}, {"dbg": 8388608 + 2097152}, {"dbg": 8388608 + 4194304}, {"drain": 0, "dbg": 0}):
+        for k, v in dict({"drain": 1}, **opts).items():
+            sc.set_option(k, v)
+        got = sc.scan(db)
+        assert got.shape == want.shape, (opts, text)
+        assert np.array_equal(got, want), (opts, text)
 
 
 @pytest.mark.parametrize("seed", range(60))
