@@ -30,7 +30,7 @@ extern "C" {
 #define RMA_MAX_SITES		16
 #define RMA_MAX_EFN_SITES	16
 #define RMA_MAX_RE		(RMA_MAX_ELEMS + 2)
-#define RMA_MAX_RE_ATOMS	64
+#define RMA_MAX_RE_ATOMS	128
 #define RMA_MAX_PAIRSETS	(RMA_MAX_ELEMS + RMA_MAX_SITES + 2)
 
 /* base codes, rnamot.h:138-143 (every non-acgtu letter is RMA_BC_N) */

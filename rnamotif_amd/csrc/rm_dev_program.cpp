@@ -10,29 +10,34 @@ namespace {
 
 const double	EPS = 1e-6;	// find_motif.c:15
 
-bool build_regex( const rma_regex_t &re, rmd_regex_t *out )
+// 0: too many states; 1: *out holds the expression; 2: *wide does (64 to 127 states) and *out only its flags
+int build_regex( const rma_regex_t &re, rmd_regex_t *out, rmd_regex2_t *wide )
 {
 	memset( out, 0, sizeof( *out ) );
+	memset( wide, 0, sizeof( *wide ) );
 	out->anchored = re.anchored;
 	out->dollar = re.dollar;
 	out->fixed_len = re.fixed_len;
+	out->wide = -1;
 	int	n = 0, run = 0, longest = 0;
 	auto add = [&]( const rma_re_atom_t &a, bool opt, bool star ) -> bool {
-		if( n >= 63 )
+		if( n >= 127 )
 			return false;
+		const int	w = n >> 6;
+		const uint64_t	bit = 1ull << ( n & 63 );
 		for( int c = 0; c < 5; c++ )
 			if( ( a.mask >> c ) & 1 )
-				out->accept[ c ] |= 1ull << n;
+				wide->accept[ c ][ w ] |= bit;
 		if( opt ){
-			out->opt |= 1ull << n;
+			wide->opt[ w ] |= bit;
 			run++;
 			longest = std::max( longest, run );
 		}else
 			run = 0;
 		if( star )
-			out->star |= 1ull << n;
+			wide->star[ w ] |= bit;
 		if( a.kind == 1 )
-			out->dot |= 1ull << n;
+			wide->dot[ w ] |= bit;
 		n++;
 		return true;
 	};
@@ -40,21 +45,31 @@ bool build_regex( const rma_regex_t &re, rmd_regex_t *out )
 		const rma_re_atom_t	&a = re.atoms[ i ];
 		for( int k = 0; k < a.lo; k++ )
 			if( !add( a, false, false ) )
-				return false;
+				return 0;
 		if( a.hi == 255 ){
 			if( !add( a, true, true ) )
-				return false;
+				return 0;
 		}else for( int k = a.lo; k < a.hi; k++ )
 			if( !add( a, true, false ) )
-				return false;
+				return 0;
 	}
+	wide->n_states = n;
+	wide->n_close = longest;
+	if( n > 63 )
+		return 2;
+	// one word is enough: the form every test of the kernels reads
+	for( int c = 0; c < 5; c++ )
+		out->accept[ c ] = wide->accept[ c ][ 0 ];
+	out->opt = wide->opt[ 0 ];
+	out->star = wide->star[ 0 ];
+	out->dot = wide->dot[ 0 ];
 	out->n_states = n;
 	out->n_close = longest;
 	if( re.anchored ){
 		while( out->n_prefix < n && !( ( out->opt >> out->n_prefix ) & 1 ) )
 			out->n_prefix++;
 	}
-	return true;
+	return 1;
 }
 
 }	// namespace
@@ -107,9 +122,19 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 	}
 	out->efn_stdbp = p->efn_stdbp >= 0 ? psmap[ p->efn_stdbp ] : 0;
 
-	for( int i = 0; i < p->n_regexes; i++ )
-		if( !build_regex( p->regexes[ i ], &out->regexes[ i ] ) )
-			FAIL( "a seq= expression expands to more than 63 positions" );
+	out->n_regexes2 = 0;
+	for( int i = 0; i < p->n_regexes; i++ ){
+		rmd_regex2_t	wide;
+		const int	kind = build_regex( p->regexes[ i ], &out->regexes[ i ], &wide );
+		if( kind == 0 )
+			FAIL( "a seq= expression expands to more than 127 positions" );
+		if( kind == 2 ){
+			if( out->n_regexes2 == RMD_MAX_RE2 )
+				FAIL( "more than %d seq= expressions of more than 63 positions", RMD_MAX_RE2 );
+			out->regexes[ i ].wide = out->n_regexes2;
+			out->regexes2[ out->n_regexes2++ ] = wide;
+		}
+	}
 
 	int	n_rules = 0;
 	auto cvt = [&]( const rma_elem_t &e, rmd_elem_t *d ) -> int {
@@ -788,6 +813,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 	out->n_rules = n_rules;
 	out->n_pairsets = n_ps;
 	out->off_regexes = int32_t( offsetof( rmd_program_t, regexes ) );
+	out->off_regexes2 = int32_t( offsetof( rmd_program_t, regexes2 ) );
 	out->off_rules = int32_t( offsetof( rmd_program_t, rules ) );
 	out->off_pairsets = int32_t( offsetof( rmd_program_t, pairsets ) );
 	out->off_pks = int32_t( offsetof( rmd_program_t, pks ) );
@@ -812,6 +838,9 @@ size_t rmd_make_image( const rmd_program_t *full, void *img )
 	hdr->off_regexes = int32_t( n );
 	memcpy( out + n, full->regexes, size_t( full->n_regexes ) * sizeof( rmd_regex_t ) );
 	n += size_t( full->n_regexes ) * sizeof( rmd_regex_t );
+	hdr->off_regexes2 = int32_t( n );		// (same alignment)
+	memcpy( out + n, full->regexes2, size_t( full->n_regexes2 ) * sizeof( rmd_regex2_t ) );
+	n += size_t( full->n_regexes2 ) * sizeof( rmd_regex2_t );
 	n = align( n, alignof( rmd_rule_t ) );
 	hdr->off_rules = int32_t( n );
 	memcpy( out + n, full->rules, size_t( full->n_rules ) * sizeof( rmd_rule_t ) );

@@ -34,6 +34,16 @@ struct rmd_regex_t {
 	int32_t	anchored, dollar;
 	int32_t	fixed_len;		// >= 0: every state mandatory (mismatch mode legal)
 	int32_t	n_prefix;		// leading states that cannot be skipped (0 unless anchored)
+	int32_t	wide, pad_;		// >= 0: the expression has 64 .. 127 states and lives in rmd_regexes2( P )[ wide ]; the
+					// members above hold no states then (no prefix, no literal, no pinned test comes from them)
+};
+
+// ... of 64 to 127 states: two words a set (round 3; the reference's own limit is the 100 bases of a strand)
+#define RMD_MAX_RE2	8
+struct rmd_regex2_t {
+	uint64_t	accept[ 5 ][ 2 ];	// [ c ][ 0 ]: states 0..63, [ c ][ 1 ]: states 64..127
+	uint64_t	opt[ 2 ], star[ 2 ], dot[ 2 ];
+	int32_t	n_states, n_close;
 };
 
 struct rmd_pairset_t {
@@ -222,8 +232,8 @@ struct rmd_program_t {
 	// of the Watson-Crick helices and 4-plex outer helices that head a search level, first element's first
 	int32_t	n_rowsets;
 	int8_t	rowset_ps[ 4 ];
-	int32_t	n_regexes, n_rules, n_pairsets, n_pks, n_tups;
-	int32_t	off_regexes, off_rules, off_pairsets, off_pks, off_tups;
+	int32_t	n_regexes, n_rules, n_pairsets, n_pks, n_tups, n_regexes2;
+	int32_t	off_regexes, off_rules, off_pairsets, off_pks, off_tups, off_regexes2;
 	int32_t	off_sites, off_efn;
 	rmd_q1filter_t	q1f;
 	rmd_chain_t	chain;		// (sites[ n_sites ], efn_sites[ n_efn ]: pools like the others)
@@ -237,6 +247,7 @@ struct rmd_program_t {
 	rmd_elem_t	lctx, rctx;
 	rmd_elem_t	elems[ RMD_MAX_ELEMS ];
 	rmd_regex_t	regexes[ RMD_MAX_RE ];
+	rmd_regex2_t	regexes2[ RMD_MAX_RE2 ];
 	rmd_rule_t	rules[ RMD_MAX_RULES ];
 	rmd_pairset_t	pairsets[ RMD_MAX_PS ];
 	rmd_pk_t	pks[ RMD_MAX_PK ];
@@ -251,6 +262,10 @@ struct rmd_program_t {
 RMD_HD const rmd_regex_t *rmd_regexes( const rmd_program_t *P )
 {
 	return reinterpret_cast<const rmd_regex_t *>( reinterpret_cast<const char *>( P ) + P->off_regexes );
+}
+RMD_HD const rmd_regex2_t *rmd_regexes2( const rmd_program_t *P )
+{
+	return reinterpret_cast<const rmd_regex2_t *>( reinterpret_cast<const char *>( P ) + P->off_regexes2 );
 }
 RMD_HD const rmd_rule_t *rmd_rules( const rmd_program_t *P )
 {

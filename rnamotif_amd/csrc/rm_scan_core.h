@@ -188,11 +188,75 @@ RMD_COLD int rmd_re_mm_step( const rmd_regex_t &re, const SQ &sq, int off, int l
 	}
 }
 
+// The same two for expressions of 64 to 127 states (rmd_regex2_t): a set of states is two words.
+struct rmd_set2_t { uint64_t lo, hi; };
+RMD_FN rmd_set2_t rmd_s2( const uint64_t *w ) { return rmd_set2_t{ w[ 0 ], w[ 1 ] }; }
+RMD_FN rmd_set2_t rmd_s2_and( rmd_set2_t a, rmd_set2_t b ) { return rmd_set2_t{ a.lo & b.lo, a.hi & b.hi }; }
+RMD_FN rmd_set2_t rmd_s2_or( rmd_set2_t a, rmd_set2_t b ) { return rmd_set2_t{ a.lo | b.lo, a.hi | b.hi }; }
+RMD_FN rmd_set2_t rmd_s2_shl1( rmd_set2_t a ) { return rmd_set2_t{ a.lo << 1, ( a.hi << 1 ) | ( a.lo >> 63 ) }; }
+RMD_FN int rmd_s2_bit( rmd_set2_t a, int i ) { return int( ( ( i < 64 ? a.lo : a.hi ) >> ( i & 63 ) ) & 1 ); }
+
+template< class SQ >
+RMD_COLD int rmd_re2_step( const rmd_regex_t &re, const rmd_regex2_t &r2, const SQ &sq, int off, int len )
+{
+	rmd_set2_t	act{ 0, 0 };
+	for( int pos = 0; ; pos++ ){
+		rmd_set2_t	f = rmd_s2_or( rmd_s2_shl1( act ), rmd_s2_and( act, rmd_s2( r2.star ) ) );
+		if( pos == 0 || !re.anchored )
+			f.lo |= 1;
+		for( int k = 0; k < r2.n_close; k++ )
+			f = rmd_s2_or( f, rmd_s2_shl1( rmd_s2_and( f, rmd_s2( r2.opt ) ) ) );
+		if( rmd_s2_bit( f, r2.n_states ) && ( !re.dollar || pos == len ) )
+			return 1;
+		if( pos == len )
+			return 0;
+		act = rmd_s2_and( f, rmd_s2( r2.accept[ rmd_code( sq, off + pos ) ] ) );
+		if( ( act.lo | act.hi ) == 0 && re.anchored )
+			return 0;
+	}
+}
+
+template< class SQ >
+RMD_COLD int rmd_re2_mm_step( const rmd_regex_t &re, const rmd_regex2_t &r2, const SQ &sq, int off, int len, int l_mm, int *n_mm )
+{
+	int	n = r2.n_states;
+	for( int st = 0; ; st++ ){
+		int	cnt = 0, ok = 1;
+		for( int j = 0; j < n; j++ ){
+			if( st + j >= len ){
+				ok = 0;
+				break;
+			}
+			if( rmd_s2_bit( rmd_s2( r2.dot ), j ) )
+				continue;
+			if( !rmd_s2_bit( rmd_s2( r2.accept[ rmd_code( sq, off + st + j ) ] ), j ) ){
+				if( ++cnt > l_mm ){
+					ok = 0;
+					break;
+				}
+			}
+		}
+		if( ok && re.dollar && st + n != len )
+			ok = 0;
+		*n_mm = cnt;
+		if( ok )
+			return 1;
+		if( re.anchored || st >= len )
+			return 0;
+	}
+}
+
 // chk_seq(), find_motif.c:1810
 template< class SQ >
 RMD_FN int rmd_chk_seq( const rmd_program_t *P, const rmd_elem_t &e, const SQ &sq, int off, int len, int *n_mm )
 {
 	const rmd_regex_t	&re = rmd_regexes( P )[ e.re ];
+	if( re.wide >= 0 ){
+		const rmd_regex2_t	&r2 = rmd_regexes2( P )[ re.wide ];
+		if( e.mismatch > 0 )
+			return rmd_re2_mm_step( re, r2, sq, off, len, e.mismatch, n_mm );
+		return rmd_re2_step( re, r2, sq, off, len );
+	}
 	if( e.mismatch > 0 )
 		return rmd_re_mm_step( re, sq, off, len, e.mismatch, n_mm );
 	return rmd_re_step( re, sq, off, len );

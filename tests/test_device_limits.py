@@ -2,7 +2,8 @@
 reference takes these descriptors; this build has no CPU search path to fall back to, so each is
 refused before any scan -- at descriptor compilation or at rma_scanner_create(), whose host part
 (rmd_build) runs before a device is asked for, so the refusals are testable here.  What is NOT
-refused any more: up to 100 elements, the reference's own limit (compile.c:49)."""
+refused any more: up to 100 elements, the reference's own limit (compile.c:49); seq= expressions of
+64 to 127 positions (round 3: a two-word automaton, tests/test_gpu_parity.py::test_long_seq_expressions)."""
 import os
 
 import pytest
@@ -13,8 +14,11 @@ CASES = [
     ("helix of up to 80 base pairs",
      "descr\n\th5(minlen=4,maxlen=80)\n\t\tss(minlen=3,maxlen=8)\n\th3\n",
      "scanner", "helix element 1 allows 80 base pairs; the device scanner takes at most 63"),
-    ("seq= that expands to more than 63 positions",
-     'descr\n\tss(minlen=70,maxlen=90,seq="^' + "acgt" * 17 + '")\n',
+    ("seq= that expands to more than 127 positions",
+     'descr\n\tss(minlen=130,maxlen=150,seq="^' + "acgt" * 32 + '")\n',
+     "scanner", "a seq= expression expands to more than 127 positions"),
+    ("seq= of more than 128 atoms",
+     'descr\n\tss(minlen=130,maxlen=150,seq="^' + "acgt" * 33 + '")\n',
      "compile", "cannot run on the device scanner: seq= pattern to"),
     ("back-reference in seq=",
      'descr\n\tss(minlen=4,maxlen=10,seq="\\(ac\\)g\\1")\n',

@@ -911,6 +911,56 @@ def test_random_descriptors_under_stress_settings(built, tmp_path, seed, gen):
     assert np.array_equal(got, want), text
 
 
+@pytest.mark.parametrize("variant", ["anchored", "floating", "mismatch", "helix", "ranges"])
+def test_long_seq_expressions(built, tmp_path, variant):
+    """seq= expressions of 64 to 127 positions (the device's position automaton takes two words a set
+    of states since round 3; round 2 refused them): planted occurrences, exact and with mismatches,
+    anchored and not, on a single strand and on a helix strand, with repeat ranges -- records equal to the oracle's."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(404)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    word = lut[rng.integers(0, 4, size=80)].tobytes().decode()
+    if variant == "anchored":
+        text = 'descr\n\tss(minlen=80,maxlen=90,seq="^%s")\n' % word
+    elif variant == "floating":
+        text = 'descr\n\tss(minlen=85,maxlen=100,seq="%s")\n' % word
+    elif variant == "mismatch":
+        text = 'descr\n\tss(len=80,seq="^%s$",mismatch=3)\n' % word
+    elif variant == "ranges":
+        text = 'descr\n\tss(minlen=72,maxlen=100,seq="^%sn\\{2,30\\}%s$")\n' % (word[:40], word[40:70])
+    else:
+        stem = lut[rng.integers(0, 4, size=12)].tobytes().decode()
+        text = 'descr\n\tss(minlen=66,maxlen=70,seq="^%s")\n\th5(len=6)\n\t\tss(minlen=4,maxlen=8)\n\th3\n' % word[:66]
+    path = tmp_path / "long.descr"
+    path.write_text(text)
+    d = R.Descriptor(["-descr", str(path)])
+    comp = bytes.maketrans(b"acgt", b"tgca")
+    seqs = []
+    for k in range(6):
+        bg = bytearray(lut[rng.integers(0, 4, size=3000 + 17 * k)].tobytes())
+        for pos in (100, 1500, 2800):
+            w = bytearray(word.encode())
+            if variant == "mismatch":
+                for j in rng.choice(80, size=k % 5, replace=False):
+                    w[j] = ord("acgt"[(b"acgt".index(w[j]) + 1) % 4])
+            if variant == "ranges":
+                w = bytearray(word[:40].encode()) + bytearray(lut[rng.integers(0, 4, size=2 + 5 * k)].tobytes()) + bytearray(word[40:70].encode())
+            if variant == "helix":
+                # the word, then a hairpin that the helix can take
+                hp = lut[rng.integers(0, 4, size=6)].tobytes()
+                w = bytearray(word[:66].encode()) + bytearray(b"a" * (k % 3)) + bytearray(hp + b"gaaaa" + hp.translate(comp)[::-1])
+            if pos + len(w) < len(bg):
+                bg[pos:pos + len(w)] = w
+        s_ = bytes(bg)
+        seqs.append(s_ if k % 2 == 0 else s_.translate(comp)[::-1])
+    want = oracle_scan(d, seqs)
+    assert want.shape[0] > 0
+    sc = R.Scanner(d)
+    got = sc.scan(sc.database(seqs))
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_random_lean_descriptors_through_the_drain_kernel(built, tmp_path, seed):
     """Generated ss / helix descriptors over planted sequence with everything the search kernel's filters let
