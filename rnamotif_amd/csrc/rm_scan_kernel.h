@@ -923,7 +923,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const bool	q1f = q1f_vecs && !( dbg & 8192 );
 	// (lean, one tile per pass, with a look-ahead chain: eight more, rmd_chain_t)
 	const bool	chain_on = LEAN && G == 1 && P->chain.on;
-	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( chain_on ? 1 : 0 );
+	// (... and, last, where each base stands -- five vectors -- when there is a best literal to look for)
+	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( chain_on ? 1 : 0 ) +
+		( P->lit_re >= 0 ? 5 : 0 );
 	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
@@ -1129,6 +1131,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( chain_vecs )
 					for( int b5 = 0; b5 < 5; b5++ )
 						reinterpret_cast<uint32_t *>( tv + b5 * pb_words )[ dd ] = is[ b5 ];
+				if( P->lit_re >= 0 )
+					for( int b5 = 0; b5 < 5; b5++ )
+						reinterpret_cast<uint32_t *>( occ + ( n_vec - 5 + b5 ) * pb_words )[ dd ] = is[ b5 ];
 				if( q1f_vecs ){
 					// strand filter of a leading 4-plex (rmd_q1filter_t): where a base stands that some quad has in
 					// second / third place, and the same for the triples of a triplex that follows
@@ -1174,17 +1179,25 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		// Best-literal filter (the reference's -O skip scan, find_motif.c:209-243, as a
 		// necessary condition): occ has a bit for every tile position where the literal
 		// starts; a start position is searched only if one lies at an allowed offset.
+		// (Round 3: a lane per 64 positions -- the bases each state of the literal takes, as the OR of their
+		// "stands here" vectors, shifted into place and ANDed -- where rounds 1 and 2 had a lane per position
+		// read the literal's bases one by one: a quarter of pk1.descr's wave cycles.  Positions outside the
+		// entry have no bit in any vector.)
 		if( lit ){
 			const rmd_regex_t	&lre = rmd_regexes( P )[ P->lit_re ];
-			const int	n_valid = p_to - p_lo;
-			for( int base = ubase; base < vec_words * 64; base += UNIT ){
-				const int	q = base + lane_id - 64;
-				bool	ok = q >= p_from - p_lo && q + lit_n <= n_valid;
-				for( int jj = 0; ok && jj < lit_n; jj++ )
-					ok = ( lre.accept[ tile[ q + jj ] ] >> jj ) & 1;
-				const unsigned long long	m = __ballot( ok );
-				if( lane_id == 0 )
-					occ[ base >> 6 ] = m;
+			const unsigned long long	*const lv = occ + size_t( n_vec - 5 ) * pb_words;
+			for( int wi = utid; wi < vec_words; wi += UNIT ){
+				unsigned long long	acc = ~0ull;
+				for( int jj = 0; jj < lit_n; jj++ ){
+					unsigned long long	lo = 0, hi = 0;
+					for( int c = 0; c < 5; c++ )
+						if( ( lre.accept[ c ] >> jj ) & 1 ){
+							lo |= lv[ c * pb_words + wi ];
+							hi |= wi + 1 < pb_words ? lv[ c * pb_words + wi + 1 ] : 0ull;
+						}
+					acc &= jj ? ( lo >> jj ) | ( hi << ( 64 - jj ) ) : lo;
+				}
+				occ[ wi ] = acc;
 			}
 			SLOT_SYNC();
 			PHASE( 1 );
