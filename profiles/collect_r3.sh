@@ -11,7 +11,7 @@ bash $R/profiles/collect.sh r3trna
 bash $R/profiles/collect.sh r3pk1 --descr $T/pk1.descr
 bash $R/profiles/collect.sh r3qutr --descr $T/qu+tr.descr
 cd /tmp
-for c in trna:$R/tests/golden/descr/trna.descr pk1:$T/pk1.descr qutr:$T/qu+tr.descr mpends:$T/mp.ends.descr ire:$T/ire.1.descr pkj12:$T/pk_j1+2.descr mixed:$R/tests/golden/descr/trna.descr,$T/pk1.descr; do
+for c in trna:$R/tests/golden/descr/trna.descr pk1:$T/pk1.descr qutr:$T/qu+tr.descr mpends:$T/mp.ends.descr ire:$T/ire.1.descr pkj12:$T/pk_j1+2.descr mixed:$T/qu+tr.descr,$T/mp.ends.descr; do
 	python3 $R/bench.py --steps 20 --warmup 3 --cpu-bases 0 --descr ${c#*:} 2> /dev/null | grep '^{"metric"' > $R/gpurun_out/r3/cfg_${c%%:*}_100M.json
 done
 python3 $R/profiles/step_breakdown.py > $R/gpurun_out/r3/step_breakdown.txt 2>&1

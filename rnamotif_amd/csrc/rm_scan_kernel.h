@@ -2095,6 +2095,25 @@ hipError_t name_( int grid, size_t lds, hipStream_t s, const rmk_search_args &a 
 	hipError_t	e = hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ); \
 	if( e != hipSuccess ) \
 		return e; \
+	/* the workgroups are persistent (tiles by ticket): no more of them than the device holds at once -- the others \
+	   would start when the first ones leave, find no tile and go (trna.descr: 2048 asked for, 1024 resident) */ \
+	{ \
+		static thread_local size_t	for_lds = ~size_t( 0 ); \
+		static thread_local int	resident = 0, for_dev = -1; \
+		int	dev = 0; \
+		( void )hipGetDevice( &dev ); \
+		if( for_lds != lds || for_dev != dev ){ \
+			int	per_cu = 0, cus = 0; \
+			resident = 0; \
+			if( hipOccupancyMaxActiveBlocksPerMultiprocessor( &per_cu, kernel, BLOCK_, lds ) == hipSuccess && \
+				hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, dev ) == hipSuccess ) \
+				resident = per_cu * cus; \
+			for_lds = lds; \
+			for_dev = dev; \
+		} \
+		if( resident > 0 && grid > resident ) \
+			grid = resident; \
+	} \
 	hipLaunchKernelGGL( kernel, dim3( grid ), dim3( BLOCK_ ), lds, s, \
 		a.d_prog, a.prog_bytes, a.qcap, a.db, a.hb, a.tile_bytes, a.dbg ); \
 	return hipGetLastError(); \

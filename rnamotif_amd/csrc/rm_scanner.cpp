@@ -191,6 +191,7 @@ struct rma_scanner {
 	hipStream_t	stream = nullptr;
 	hipEvent_t	ev[ 5 ] = { nullptr, nullptr, nullptr, nullptr, nullptr };	// search kernel's start / end, efn kernel's, [4]: the search kernel's end when a drain kernel follows
 	bool	drained = false;		// the last launch had a drain kernel
+	bool	searched = false, efn_ran = false;	// a search kernel was launched at all; the last scan had an efn kernel
 	rma_efn2data_t	*d_efn2 = nullptr;	// efn2() tables, global memory
 	bool	need_efn2 = false;
 	rmd_program_t	*d_prog = nullptr;	// compact image, prog_bytes long
@@ -964,6 +965,8 @@ static int launch_search( rma_scanner_t *sc, char *err, size_t errlen )
 	HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
 	HIPCHK( rmk_launch_search( f.inst, f.grid, f.lds, sc->stream, a ) );
 	sc->drained = drain;
+	sc->searched = true;
+	sc->efn_ran = false;
 	if( drain ){	// the items the search kernel left in the list: walked by a kernel of their own
 		HIPCHK( hipEventRecord( sc->ev[ 4 ], sc->stream ) );
 		a.tile_bytes = sc->drain_nib;
@@ -1207,6 +1210,7 @@ static int launch_efn( rma_scanner_t *sc, int64_t count, char *err, size_t errle
 	const int64_t	blocks = std::min<int64_t>( ( count + EFN_BLOCK - 1 ) / EFN_BLOCK, sc->grid_blocks / 8 );
 	rmk_efn_args	a{ sc->d_prog, view_of( sc->fly.db, sc->fly.lay ), sc->d_hits, ( long long )count,
 		sc->have_efn ? sc->d_t16 : nullptr, sc->d_tlkey, sc->d_loginc, sc->d_efn2 };
+	sc->efn_ran = true;
 	HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
 	HIPCHK( rmk_launch_efn( int( blocks ), sc->stream, a ) );
 	HIPCHK( hipEventRecord( sc->ev[ 3 ], sc->stream ) );
@@ -1257,18 +1261,15 @@ extern "C" int rma_scanner_last_kernel_ms( rma_scanner_t *sc, float ms[ 3 ], cha
 	HIPCHK( hipSetDevice( sc->device ) );
 	ms[ 0 ] = ms[ 1 ] = ms[ 2 ] = 0;
 	HIPCHK( hipStreamSynchronize( sc->stream ) );
-	if( hipEventQuery( sc->ev[ 1 ] ) != hipSuccess )
+	if( !sc->searched )
 		return 0;		// (nothing was launched yet)
 	if( sc->drained ){
 		HIPCHK( hipEventElapsedTime( &ms[ 0 ], sc->ev[ 0 ], sc->ev[ 4 ] ) );
 		HIPCHK( hipEventElapsedTime( &ms[ 1 ], sc->ev[ 4 ], sc->ev[ 1 ] ) );
 	}else
 		HIPCHK( hipEventElapsedTime( &ms[ 0 ], sc->ev[ 0 ], sc->ev[ 1 ] ) );
-	if( hipEventQuery( sc->ev[ 3 ] ) == hipSuccess && hipEventQuery( sc->ev[ 2 ] ) == hipSuccess ){
-		float	e = 0;
-		if( hipEventElapsedTime( &e, sc->ev[ 2 ], sc->ev[ 3 ] ) == hipSuccess && e >= 0 )
-			ms[ 2 ] = e;
-	}
+	if( sc->efn_ran )
+		HIPCHK( hipEventElapsedTime( &ms[ 2 ], sc->ev[ 2 ], sc->ev[ 3 ] ) );
 	return 0;
 }
 
