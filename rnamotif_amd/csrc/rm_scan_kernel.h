@@ -1415,7 +1415,96 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				return rows_win( pb, pb_words, tile, p_lo, hl0, lim, ends5, szero, top - r0 - 63, lo );
 			};
 			int	n_wait = 0;		// pseudoknot pre-filter: start positions of this wave that wait in cbuf
-			for( int j = 0; j < n_pos; j += UNIT ){
+			// one start position per lane: the end positions that pass the first-pairs test are queued
+			auto	body = [ & ]( const int rel, const bool valid_in ){
+				const int	szero = z0 + rel;
+				bool	valid = valid_in;
+				if( q1f && valid ){
+					// no place within reach for the 4-plex' second strand: nothing starts here
+					const int	bq = szero - p_lo + 64;
+					valid = ( xv[ 2 * pb_words + ( bq >> 6 ) ] >> ( bq & 63 ) ) & 1;
+				}
+				int	hi = 0, lo = 1;
+				if( valid )
+					rmd_level0_range( P, szero, slen, &hi, &lo );
+				for( int r0 = 0; r0 < n_rank; r0 += 64 ){
+					unsigned long long	W = 0;
+					if( valid && r0 <= hi - lo ){
+						W = win( szero, hi, r0, lo );
+						if( q1f && W ){
+							// ... and end positions before which no third strand can stand (bit i: end hi - r0 - 63 + i)
+							const int	bq = hi - r0 - 63 - p_lo + 64;
+							if( bq >= 0 && bq + 96 <= vec_words * 64 )
+								W &= bits64( xv + 3 * pb_words, bq );
+						}
+					}
+					while( __ballot( W != 0 ) ){
+						const bool	has = W != 0;
+						const int	i = has ? __ffsll( W ) - 1 : 0;
+						const int	r = r0 + 63 - i;
+						// (the pinned tail helix of the interior, rmd_tail_ok(), is left to pass B:
+						// tested here it costs more in this divergent loop than it saves there)
+						QPUSH( has, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
+						W &= W - 1;
+					}
+				}
+			};
+			bool	by_words = false;
+			if constexpr( LEAN && G == 1 ){
+			if( chain ){
+				// The look-ahead leaves a start position in fourteen (trna.descr).  They are taken from the words
+				// of its vector -- a lane looks at 16 positions at once and hands on the bits that are set --
+				// instead of position by position (36 rounds of the wave per tile, each for four or five
+				// survivors: the rounds, not the survivors, were where the pre-filter's time went), collected
+				// per wave and searched 64 at a time, so that the row windows run with their lanes full.
+				by_words = true;
+				__shared__ uint16_t	s_cbuf2[ BLOCK / 64 ][ 128 ];
+				uint16_t	*const cbuf = s_cbuf2[ tid >> 6 ];
+				auto	take = [ & ](){
+					__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+					const int	n_take = n_wait < 64 ? n_wait : 64;
+					const bool	have = lane_id < n_take;
+					const int	rel = have ? int( cbuf[ lane_id ] ) : 0;
+					const int	rest = n_wait - n_take;
+					const int	moved = lane_id < rest ? int( cbuf[ n_take + lane_id ] ) : 0;
+					__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+					if( lane_id < rest )
+						cbuf[ lane_id ] = uint16_t( moved );
+					n_wait = rest;
+					body( rel, have );
+				};
+				for( int q0 = 0; q0 < n_pos; q0 += UNIT * 16 ){
+					const int	rel_lo = q0 + utid * 16;
+					unsigned	m = 0;
+					if( rel_lo < n_pos ){
+						// (n_pos covers what the position-by-position test asks: inside the tile, the entry and the slice)
+						m = unsigned( bits64( xv, z0 + rel_lo - p_lo + 64 ) ) & 0xffffu;
+						if( n_pos - rel_lo < 16 )
+							m &= ( 1u << ( n_pos - rel_lo ) ) - 1u;
+					}
+					while( __ballot( m != 0 ) ){
+						bool	ok = m != 0;
+						const int	rel = rel_lo + ( ok ? __ffs( int( m ) ) - 1 : 0 );
+						m &= m - 1;
+						if( ok )
+							LIT_OK( z0 + rel, ok );
+						const unsigned long long	mv = __ballot( ok );
+						if( ok )
+							cbuf[ n_wait + __popcll( mv & lt_mask ) ] = uint16_t( rel );
+						n_wait += __popcll( mv );
+						while( n_wait >= 64 )
+							take();
+					}
+				}
+				while( n_wait > 0 )
+					take();
+			}
+			}
+			for( int j = 0; j < ( by_words ? 0 : n_pos ); j += UNIT ){
 				const int	rel0 = j + utid;
 				bool	valid0 = rel0 < T && z0 + rel0 <= slen - P->dminlen && z0 + rel0 < pos_hi;
 				if( valid0 )
@@ -1535,75 +1624,6 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 							}else
 								QPUSH( any, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
 						}while( 0 );
-					}
-					continue;
-				}
-				}
-				// one start position per lane: the end positions that pass the first-pairs test are queued
-				auto	body = [ & ]( const int rel, const bool valid_in ){
-					const int	szero = z0 + rel;
-					bool	valid = valid_in;
-					if( q1f && valid ){
-						// no place within reach for the 4-plex' second strand: nothing starts here
-						const int	bq = szero - p_lo + 64;
-						valid = ( xv[ 2 * pb_words + ( bq >> 6 ) ] >> ( bq & 63 ) ) & 1;
-					}
-					int	hi = 0, lo = 1;
-					if( valid )
-						rmd_level0_range( P, szero, slen, &hi, &lo );
-					for( int r0 = 0; r0 < n_rank; r0 += 64 ){
-						unsigned long long	W = 0;
-						if( valid && r0 <= hi - lo ){
-							W = win( szero, hi, r0, lo );
-							if( q1f && W ){
-								// ... and end positions before which no third strand can stand (bit i: end hi - r0 - 63 + i)
-								const int	bq = hi - r0 - 63 - p_lo + 64;
-								if( bq >= 0 && bq + 96 <= vec_words * 64 )
-									W &= bits64( xv + 3 * pb_words, bq );
-							}
-						}
-						while( __ballot( W != 0 ) ){
-							const bool	has = W != 0;
-							const int	i = has ? __ffsll( W ) - 1 : 0;
-							const int	r = r0 + 63 - i;
-							// (the pinned tail helix of the interior, rmd_tail_ok(), is left to pass B:
-							// tested here it costs more in this divergent loop than it saves there)
-							QPUSH( has, ( unsigned( rel ) << 16 ) | unsigned( r ), szero, r, 1 );
-							W &= W - 1;
-						}
-					}
-				};
-				if constexpr( LEAN && G == 1 ){
-				if( chain ){
-					// The look-ahead leaves a start position in twenty (trna.descr): collected per wave and
-					// taken 64 at a time, so that the row windows run with their lanes full.
-					__shared__ uint16_t	s_cbuf2[ BLOCK / 64 ][ 128 ];
-					uint16_t	*const cbuf = s_cbuf2[ tid >> 6 ];
-					if( valid0 ){
-						const int	bq = z0 + rel0 - p_lo + 64;
-						valid0 = ( xv[ bq >> 6 ] >> ( bq & 63 ) ) & 1;
-					}
-					const unsigned long long	mv = __ballot( valid0 );
-					if( valid0 )
-						cbuf[ n_wait + __popcll( mv & lt_mask ) ] = uint16_t( rel0 );
-					n_wait += __popcll( mv );
-					const bool	last_j = j + UNIT >= n_pos;
-					while( n_wait >= 64 || ( last_j && n_wait > 0 ) ){
-						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-						__builtin_amdgcn_wave_barrier();
-						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-						const int	n_take = n_wait < 64 ? n_wait : 64;
-						const bool	have = lane_id < n_take;
-						const int	rel = have ? int( cbuf[ lane_id ] ) : 0;
-						const int	rest = n_wait - n_take;
-						const int	moved = lane_id < rest ? int( cbuf[ n_take + lane_id ] ) : 0;
-						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-						__builtin_amdgcn_wave_barrier();
-						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-						if( lane_id < rest )
-							cbuf[ lane_id ] = uint16_t( moved );
-						n_wait = rest;
-						body( rel, have );
 					}
 					continue;
 				}
