@@ -923,8 +923,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const bool	q1f = q1f_vecs && !( dbg & 8192 );
 	// (lean, one tile per pass, with a look-ahead chain: eight more, rmd_chain_t)
 	const bool	chain_on = LEAN && G == 1 && P->chain.on;
+	// (a vector of the start positions worth a look: what the look-ahead chain leaves, or where the best literal is within reach)
+	const bool	sv_on = LEAN && G == 1 && ( P->chain.on || P->lit_re >= 0 );
 	// (... and, last, where each base stands -- five vectors -- when there is a best literal to look for)
-	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( chain_on ? 1 : 0 ) +
+	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( sv_on ? 1 : 0 ) +
 		( P->lit_re >= 0 ? 5 : 0 );
 	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
@@ -1218,6 +1220,28 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			} \
 		} }while( 0 )
 #define LIT_OK( szero_, res_ )	LIT_IN( ( szero_ ) + P->lit_lo, ( szero_ ) + lit_hi, res_ )
+		// LIT_OK for the 64 start positions from bit x of the vectors on, or more (undecided near the vectors' end: kept)
+		auto	lit_starts = [ & ]( int x ) -> unsigned long long {
+			if( !lit )
+				return ~0ull;
+			const int	n = lit_hi - P->lit_lo + 1;
+			unsigned long long	r = 0;
+			for( int k = 0; k < n && ~r; k += 64 ){
+				const int	idx = x + P->lit_lo + k, m = rmd_imin( 64, n - k );
+				if( idx < 0 || ( idx >> 6 ) + 2 >= pb_words )
+					return ~0ull;
+				unsigned long long	lo = bits64( occ, idx ), hi = bits64( occ, idx + 64 );
+				// (bit i: any of the bits i .. i + m - 1 of hi:lo)
+				for( int have = 1; have < m; ){
+					const int	st = rmd_imin( have, m - have );
+					lo |= ( lo >> st ) | ( hi << ( 64 - st ) );
+					hi |= hi >> st;
+					have += st;
+				}
+				r |= lo;
+			}
+			return r;
+		};
 
 		// push( pred, item ): one ballot + prefix count per call; overflow is searched in place
 #define QPUSH( pred, item, szero_, r0_, cnt_ )	do{ \
@@ -1394,7 +1418,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				unsigned long long	r = 0;
 				for( int h = C.s_lo; h <= C.s_hi && ~r; h++ )
 					r |= peek( g1, x + h );
-				xv[ wi ] = r;
+				xv[ wi ] = r & lit_starts( x );
 			}
 			__syncthreads();
 		}
@@ -1451,7 +1475,16 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			};
 			bool	by_words = false;
 			if constexpr( LEAN && G == 1 ){
-			if( chain ){
+			bool	start_vec = chain;
+			if( !chain && lit && sv_on && !( dbg & 33554432 ) ){
+				// no look-ahead chain, but a best literal: the start positions that have it within reach, as a vector
+				// (ire.descr, mp.ends.descr: one position in some hundred -- the same rounds saved)
+				for( int wi = tid; wi < vec_words; wi += BLOCK )
+					xv[ wi ] = lit_starts( wi * 64 );
+				__syncthreads();
+				start_vec = true;
+			}
+			if( start_vec ){
 				// The look-ahead leaves a start position in fourteen (trna.descr).  They are taken from the words
 				// of its vector -- a lane looks at 16 positions at once and hands on the bits that are set --
 				// instead of position by position (36 rounds of the wave per tile, each for four or five
