@@ -1663,8 +1663,37 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 				body( rel0, valid0 );
 			}
-		}else
-		for( int j = 0; j < n_pos; j += UNIT ){
+		}else{
+		bool	by_words = false;
+		if constexpr( LEAN && G == 1 ){
+		if( lit && sv_on && !quick && !split_ranks && !( dbg & 33554432 ) ){
+			// whole start positions are queued, and only those with the best literal within reach (ire.descr: one in
+			// 170): taken from the words of that vector, as above, not position by position
+			by_words = true;
+			for( int wi = tid; wi < vec_words; wi += BLOCK )
+				xv[ wi ] = lit_starts( wi * 64 );
+			__syncthreads();
+			for( int q0 = 0; q0 < n_pos; q0 += UNIT * 16 ){
+				const int	rel_lo = q0 + utid * 16;
+				unsigned	m = 0;
+				if( rel_lo < n_pos ){
+					m = unsigned( bits64( xv, z0 + rel_lo - p_lo + 64 ) ) & 0xffffu;
+					if( n_pos - rel_lo < 16 )
+						m &= ( 1u << ( n_pos - rel_lo ) ) - 1u;
+				}
+				while( __ballot( m != 0 ) ){
+					bool	pred = m != 0;
+					const int	rel = rel_lo + ( pred ? __ffs( int( m ) ) - 1 : 0 ), szero = z0 + rel;
+					m &= m - 1;
+					if( pred )
+						LIT_OK( szero, pred );
+					pred = pred && ( !e0_at_szero || rmd_prefix_ok( P, e0, sq, szero ) );
+					QPUSH( pred, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
+				}
+			}
+		}
+		}
+		for( int j = 0; j < ( by_words ? 0 : n_pos ); j += UNIT ){
 			const int	rel = j + utid;
 			const int	szero = z0 + rel;
 			bool	valid = rel < T && szero <= slen - P->dminlen && szero < pos_hi;
@@ -1707,6 +1736,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					QPUSH( pred, ( unsigned( rel ) << 16 ) | 0xffffu, szero, 0, RMD_ALL_RANKS );
 				}
 			}
+		}
 		}
 #undef QPUSH
 #undef LIT_OK
