@@ -924,7 +924,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// (lean, one tile per pass, with a look-ahead chain: eight more, rmd_chain_t)
 	const bool	chain_on = LEAN && G == 1 && P->chain.on;
 	// (a vector of the start positions worth a look: what the look-ahead chain leaves, or where the best literal is within reach)
-	const bool	sv_on = LEAN && G == 1 && ( P->chain.on || P->lit_re >= 0 );
+	const bool	sv_on = ( LEAN && G == 1 && ( P->chain.on || P->lit_re >= 0 ) ) || ( !LEAN && P->lit_re >= 0 );
 	// (... and, last, where each base stands -- five vectors -- when there is a best literal to look for)
 	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( sv_on ? 1 : 0 ) +
 		( P->lit_re >= 0 ? 5 : 0 );
@@ -1537,9 +1537,69 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					take();
 			}
 			}
-			for( int j = 0; j < ( by_words ? 0 : n_pos ); j += UNIT ){
-				const int	rel0 = j + utid;
-				bool	valid0 = rel0 < T && z0 + rel0 <= slen - P->dminlen && z0 + rel0 < pos_hi;
+			// (general instance, a pseudoknot's first helix at the start position and a best literal: the start positions
+			// worth a look come from the words of a vector -- the literal within reach AND the helix' anchored seq= prefix,
+			// both from the "stands here" vectors -- one bit per lane and round, instead of position by position)
+			bool	pk_words = false, pk_done = false;
+			unsigned	pk_m = 0;
+			int	pk_q0 = 0, pk_lo = 0;
+			if constexpr( !LEAN ){
+			if( pk0 && lit && sv_on && !( dbg & 33554432 ) ){
+				unsigned long long	*const sv = occ + size_t( n_vec - 6 ) * pb_words;
+				const unsigned long long	*const lv = occ + size_t( n_vec - 5 ) * pb_words;
+				const bool	pre = e0.re >= 0 && e0.mismatch == 0;
+				const rmd_regex_t	&pre_re = rmd_regexes( P )[ pre ? e0.re : 0 ];
+				const int	n_pre = pre ? rmd_imin( pre_re.n_prefix, e0.minlen ) : 0;
+				for( int wi = utid; wi < vec_words; wi += UNIT ){
+					unsigned long long	acc = lit_starts( wi * 64 );
+					for( int jj = 0; jj < n_pre && acc; jj++ ){
+						unsigned long long	lo = 0, hi = 0;
+						for( int c = 0; c < 5; c++ )
+							if( ( pre_re.accept[ c ] >> jj ) & 1 ){
+								lo |= lv[ c * pb_words + wi ];
+								hi |= wi + 1 < pb_words ? lv[ c * pb_words + wi + 1 ] : ~0ull;
+							}
+						acc &= jj ? ( lo >> jj ) | ( hi << ( 64 - jj ) ) : lo;
+					}
+					sv[ wi ] = acc;
+				}
+				SLOT_SYNC();
+				pk_words = true;
+			}
+			}
+			for( int j = 0; ; ){
+				int	rel0 = 0;
+				bool	valid0 = false, last_j = false;
+				if( pk_words ){
+					if( pk_done )
+						break;
+					const unsigned long long	*const sv = occ + size_t( n_vec - 6 ) * pb_words;
+					while( __ballot( pk_m != 0 ) == 0 && pk_q0 < n_pos ){
+						pk_lo = pk_q0 + utid * 16;
+						pk_m = 0;
+						if( pk_lo < n_pos ){
+							pk_m = unsigned( bits64( sv, z0 + pk_lo - p_lo + 64 ) ) & 0xffffu;
+							if( n_pos - pk_lo < 16 )
+								pk_m &= ( 1u << ( n_pos - pk_lo ) ) - 1u;
+						}
+						pk_q0 += UNIT * 16;
+					}
+					if( __ballot( pk_m != 0 ) == 0 ){
+						pk_done = true;		// (one more round, without positions: what still waits is searched)
+						last_j = true;
+					}else{
+						valid0 = pk_m != 0;
+						rel0 = pk_lo + ( valid0 ? __ffs( int( pk_m ) ) - 1 : 0 );
+						pk_m &= pk_m - 1;
+					}
+				}else{
+					if( j >= ( by_words ? 0 : n_pos ) )
+						break;
+					rel0 = j + utid;
+					valid0 = rel0 < T && z0 + rel0 <= slen - P->dminlen && z0 + rel0 < pos_hi;
+					last_j = j + UNIT >= n_pos;
+					j += UNIT;
+				}
 				if( valid0 )
 					LIT_OK( z0 + rel0, valid0 );
 				if constexpr( !LEAN ){
@@ -1554,7 +1614,6 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					if( valid0 )
 						cbuf[ n_wait + __popcll( mv & lt_mask ) ] = uint16_t( rel0 );
 					n_wait += __popcll( mv );
-					const bool	last_j = j + UNIT >= n_pos;
 					while( n_wait >= 64 || ( last_j && n_wait > 0 ) ){
 						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
 						__builtin_amdgcn_wave_barrier();

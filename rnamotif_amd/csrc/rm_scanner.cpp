@@ -323,7 +323,7 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 	// (lean with a look-ahead chain: one more -- the start positions that remain; the chain's other vectors
 	// borrow the place of the search records, which pass A does not use)
 	// (... and five when the descriptor has a best literal: where each base stands, for the literal's occurrence vector)
-	const size_t	pb_bytes = ( ( lean ? 6 + ( ( dp.chain.on || dp.lit_re >= 0 ) && group == 1 ? 1 : 0 ) : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? ( dp.q1f.t_on ? 9 : 4 ) : 0 ) ) +
+	const size_t	pb_bytes = ( ( lean ? 6 + ( ( dp.chain.on || dp.lit_re >= 0 ) && group == 1 ? 1 : 0 ) : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? ( dp.q1f.t_on ? 9 : 4 ) : 0 ) + ( dp.lit_re >= 0 ? 1 : 0 ) ) +
 			( dp.lit_re >= 0 ? 5 : 0 ) ) *
 		( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
