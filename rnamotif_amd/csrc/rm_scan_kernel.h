@@ -1474,9 +1474,25 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 			};
 			bool	by_words = false;
-			if constexpr( LEAN && G == 1 ){
+			if constexpr( ( LEAN && G == 1 ) || !LEAN ){
 			bool	start_vec = chain;
-			if( !chain && lit && sv_on && !( dbg & 33554432 ) ){
+			const unsigned long long	*src = xv;		// the vector of start positions worth a look
+			if constexpr( !LEAN ){
+				if( q1f && !pk0 && !( dbg & 33554432 ) ){
+					// a 4-plex at the head of the search list: the start positions from which its second strand can be
+					// reached (the strand filter's A), with the best literal within reach if there is one
+					src = xv + 2 * pb_words;
+					if( lit && sv_on ){
+						unsigned long long	*const sv = occ + size_t( n_vec - 6 ) * pb_words;
+						for( int wi = utid; wi < vec_words; wi += UNIT )
+							sv[ wi ] = xv[ 2 * pb_words + wi ] & lit_starts( wi * 64 );
+						SLOT_SYNC();
+						src = sv;
+					}
+					start_vec = true;
+				}
+			}
+			if( LEAN && !chain && lit && sv_on && !( dbg & 33554432 ) ){
 				// no look-ahead chain, but a best literal: the start positions that have it within reach, as a vector
 				// (ire.descr, mp.ends.descr: one position in some hundred -- the same rounds saved)
 				for( int wi = tid; wi < vec_words; wi += BLOCK )
@@ -1515,7 +1531,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					unsigned	m = 0;
 					if( rel_lo < n_pos ){
 						// (n_pos covers what the position-by-position test asks: inside the tile, the entry and the slice)
-						m = unsigned( bits64( xv, z0 + rel_lo - p_lo + 64 ) ) & 0xffffu;
+						m = unsigned( bits64( src, z0 + rel_lo - p_lo + 64 ) ) & 0xffffu;
 						if( n_pos - rel_lo < 16 )
 							m &= ( 1u << ( n_pos - rel_lo ) ) - 1u;
 					}
