@@ -229,7 +229,7 @@ __device__ inline void wave_emit_pending( const rmd_program_t *P, const LdsRecs<
 	for( unsigned long long em = __ballot( k >= 0 && st.pending ); em; em &= em - 1 ){
 		const int	l = __ffsll( em ) - 1;
 		const LdsRecs<BLOCK>	lrl{ lr.lo + ( l - lane_id ), lr.hi + ( l - lane_id ) };
-		if( lane_id == l && st.only_hl >= 0 && st.order >= ( 1 << PIECE_ORDER_BITS ) )
+		if( lane_id == l && st.only_hl >= 0 && !P->ord_ok && st.order >= ( 1 << PIECE_ORDER_BITS ) )
 			atomicMax( hb.ticket + 2, 1ull );	// (the pieces' order words would run into each other)
 		bool	stored;
 		if constexpr( INLINE )

@@ -137,6 +137,7 @@ struct Options {
 	int	pool = -1;		// -1: by the descriptor, 0: pass B tile by tile
 	int	pool_min = 1024, pool_refill = 48;
 	int	drain = 1;		// pooled instance: the items are walked by a kernel of their own (0: by the workgroup that found them)
+	int	glist = 0;		// > 0: items of the drain kernel's list (tests: a list that overflows), 0: by the database's size
 	int	host_sort = 0, timing = 0;
 	int	short_force = -1;	// -1: by the mean entry length, 0 never, 1 always groups of small tiles
 	int	tile = 0, qcap = 0;	// forced tile size / queue entries, 0: computed
@@ -154,6 +155,7 @@ struct Options {
 		pool_min = std::max( 1, env_int( "RNAMOTIF_POOL_MIN", 1024 ) );
 		pool_refill = env_int( "RNAMOTIF_POOL_REFILL", 48 );
 		drain = env_int( "RNAMOTIF_DRAIN", 1 );
+		glist = env_int( "RNAMOTIF_GLIST", 0 );
 		host_sort = env_int( "RNAMOTIF_HOSTSORT", 0 );
 		timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
 		if( const char *f = getenv( "RNAMOTIF_SHORT" ) )
@@ -519,12 +521,13 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 	else if( n == "pool_min" ) o.pool_min = std::max( 1, value );
 	else if( n == "pool_refill" ) o.pool_refill = value;
 	else if( n == "drain" ) o.drain = value;
+	else if( n == "glist" ) o.glist = std::max( 0, value );
 	else if( n == "host_sort" ) o.host_sort = value;
 	else if( n == "timing" ) o.timing = value;
 	else if( n == "short" ) o.short_force = value;
 	else{
 		snprintf( err, errlen, "rma_scanner_set_option: no option '%s' that can change after creation "
-			"(dbg, pool, pool_min, pool_refill, drain, host_sort, timing, short)", n.c_str() );
+			"(dbg, pool, pool_min, pool_refill, drain, glist, host_sort, timing, short)", n.c_str() );
 		return 1;
 	}
 	return 0;
@@ -1108,9 +1111,10 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	if( pooled ){
 		// The list of the drain kernel: room for an item per 32 bases (trna.descr leaves one per 70 before the
 		// stem-loop tests and one per 4500 after them); a workgroup that finds it full walks its own items.
-		const int	want = !sc->opt.drain ? 0 : int( std::min<long long>( std::max<long long>( db->sum_slen / 32, 1 << 18 ), 1 << 24 ) );
+		const int	want = !sc->opt.drain ? 0 : sc->opt.glist > 0 ? sc->opt.glist :
+			int( std::min<long long>( std::max<long long>( db->sum_slen / 32, 1 << 18 ), 1 << 24 ) );
 		const int	cap = sc->opt.pool_min + lay->qcap + sc->spill_cap;
-		if( cap > sc->pool_cap || want > sc->glist_cap || ( want == 0 && sc->glist_cap != 0 ) ){
+		if( cap > sc->pool_cap || want > sc->glist_cap || ( want == 0 && sc->glist_cap != 0 ) || ( sc->opt.glist > 0 && want != sc->glist_cap ) ){
 			HIPCHK( hipStreamSynchronize( sc->stream ) );
 			( void )hipFree( sc->d_pool );
 			sc->d_pool = nullptr;

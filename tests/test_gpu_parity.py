@@ -208,9 +208,11 @@ def test_pooled_and_tile_by_tile_pass_b_agree(built, workdir, gbrna, name):
     db = sc.database(seqs)
     # drain 0: every workgroup walks its own items; dbg 2097152: the drain kernel's items stay whole (no pieces);
     # 4194304: no subtrees handed to idle lanes; 8388608: everything a workgroup holds at the end goes to the list
-    base = {"pool": -1, "pool_min": 1024, "pool_refill": 48, "drain": 1, "dbg": 0}
+    # glist: items of the drain kernel's list (7: it overflows at once and the workgroups that find no room walk their own items)
+    base = {"pool": -1, "pool_min": 1024, "pool_refill": 48, "drain": 1, "dbg": 0, "glist": 0}
     for opts in ({}, {"pool": 0}, {"pool_min": 8, "pool_refill": 1}, {"pool_min": 100000}, {"drain": 0}, {"dbg": 2097152},
-                 {"dbg": 4194304}, {"dbg": 8388608}, {"dbg": 8388608 + 4194304 + 2097152}, {"dbg": 8388608, "pool_refill": 1}):
+                 {"dbg": 4194304}, {"dbg": 8388608}, {"dbg": 8388608 + 4194304 + 2097152}, {"dbg": 8388608, "pool_refill": 1},
+                 {"dbg": 8388608, "glist": 7}, {"glist": 1}, {"dbg": 8388608, "glist": 300}):
         for k, v in dict(base, **opts).items():
             sc.set_option(k, v)
         got = sc.scan(db)
