@@ -138,6 +138,7 @@ struct Options {
 	int	pool_min = 1024, pool_refill = 48;
 	int	drain = 1;		// pooled instance: the items are walked by a kernel of their own (0: by the workgroup that found them)
 	int	glist = 0;		// > 0: items of the drain kernel's list (tests: a list that overflows), 0: by the database's size
+	int	drain_waves = 0;	// > 0: workgroups (of one wave) of the drain kernel per CU instead of what LDS and registers allow
 	int	host_sort = 0, timing = 0;
 	int	short_force = -1;	// -1: by the mean entry length, 0 never, 1 always groups of small tiles
 	int	tile = 0, qcap = 0;	// forced tile size / queue entries, 0: computed
@@ -156,6 +157,7 @@ struct Options {
 		pool_refill = env_int( "RNAMOTIF_POOL_REFILL", 48 );
 		drain = env_int( "RNAMOTIF_DRAIN", 1 );
 		glist = env_int( "RNAMOTIF_GLIST", 0 );
+		drain_waves = env_int( "RNAMOTIF_DRAIN_WAVES", 0 );
 		host_sort = env_int( "RNAMOTIF_HOSTSORT", 0 );
 		timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
 		if( const char *f = getenv( "RNAMOTIF_SHORT" ) )
@@ -522,12 +524,13 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 	else if( n == "pool_refill" ) o.pool_refill = value;
 	else if( n == "drain" ) o.drain = value;
 	else if( n == "glist" ) o.glist = std::max( 0, value );
+	else if( n == "drain_waves" ) o.drain_waves = std::max( 0, value );
 	else if( n == "host_sort" ) o.host_sort = value;
 	else if( n == "timing" ) o.timing = value;
 	else if( n == "short" ) o.short_force = value;
 	else{
 		snprintf( err, errlen, "rma_scanner_set_option: no option '%s' that can change after creation "
-			"(dbg, pool, pool_min, pool_refill, drain, glist, host_sort, timing, short)", n.c_str() );
+			"(dbg, pool, pool_min, pool_refill, drain, glist, drain_waves, host_sort, timing, short)", n.c_str() );
 		return 1;
 	}
 	return 0;
@@ -1128,7 +1131,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 		sc->drain_nib = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;	// (n_dw above: at most 32)
 		sc->drain_lds = size_t( sc->prog_bytes ) + size_t( sc->drain_nib + dp.n_searches ) * 64 * sizeof( uint32_t ) + size_t( dp.n_searches ) * 64 * sizeof( uint16_t );
 		const int	per_cu = int( std::min<size_t>( 4 * SEARCH_WAVES_PER_SIMD, ( 160 * 1024 ) / ( sc->drain_lds + 64 ) ) );
-		sc->drain_grid = ( sc->grid_blocks / 8 ) * std::max( 1, per_cu );
+		sc->drain_grid = ( sc->grid_blocks / 8 ) * std::max( 1, sc->opt.drain_waves > 0 ? std::min( sc->opt.drain_waves, per_cu ) : per_cu );
 	}
 	// the kernel instance: lean (pooled, one tile or a group of small ones per pass), or the general one
 	// compiled for the kinds of element the descriptor has
