@@ -301,6 +301,18 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 				back = s;
 		}
 	}
+	// ... and the lean path's own (rmd_elem_t::lean_back_s): also a single strand of one length that is followed by others
+	{
+		int	back = -1;
+		for( int s = 0; s < p->n_searches; s++ ){
+			rmd_elem_t	&e = out->elems[ p->searches[ s ] ];
+			e.lean_back_s = int8_t( back );
+			e.ord_pad_ = 0;
+			const bool	one = e.type == RMA_T_SS && ( !e.loop || ( s > 0 && e.maxglen != RMA_UNBOUNDED && e.minglen == e.maxglen ) );
+			if( !one )
+				back = s;
+		}
+	}
 	// split level: the helices at the head of the search list are where most start positions die
 	{
 		int	run = 0;

@@ -99,7 +99,11 @@ struct rmd_elem_t {
 	// below it multiplied out).  rmd_program_t::ord_ok says the number fits 31 bits; then the kernels store it
 	// as the order word and may walk an item in pieces, in any order (both sorts renumber the order words).
 	int32_t	ord_stride;
-	int16_t	ord_nlen, ord_pad_;
+	int16_t	ord_nlen;
+	// lean path: the level to go back to when this one is exhausted -- the nearest one below it that may have
+	// another alternative.  A single strand of one length (its one end position is taken) has none: going
+	// back to it only to learn that costs a step of the walk, six of trna.descr's eleven levels are such.
+	int8_t	lean_back_s, ord_pad_;
 };
 
 // First-tuple masks of a triplex / 4-plex pair table: match_triplex()/match_4plex() give up at

@@ -917,7 +917,7 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 				}
 			}
 			if( r.sd < lo )
-				return k - 1;
+				return stp.lean_back_s;		// (k - 1, or further back past levels that have no other alternative)
 			cur = r.sd--;
 			if( k == st.hm_level ){
 				// an end the caller's tests have ruled out for this length of the first element
