@@ -290,6 +290,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 	RMD_COUNT( 4 );
 	uint64_t	c = 0, m = 0;
 	int	hl, mpr, l_bpr, mm5 = *pmm5, mm3 = *pmm3;
+	const uint32_t	mat2 = rmd_pairsets( P )[ stp.pairset ].mat2;	// (RM_paired :1291 for every pair below: the table once)
 
 	if( stp.minlen == 0 ){
 		int	ok = 1;
@@ -298,7 +299,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 		if( ok && ( stp3.re < 0 || rmd_chk_seq( P, stp3, sq, s3 + 1, 0, &mm3 ) ) )
 			c |= 1;
 	}
-	if( rmd_paired( P, stp.pairset, rmd_code( sq, s5 ), rmd_code( sq, s3 ) ) ){
+	if( ( ( mat2 >> ( rmd_code( sq, s5 ) * 5 + rmd_code( sq, s3 ) ) ) & 1u ) ){
 		hl = 1;
 		mpr = 0;
 		l_bpr = 1;
@@ -332,7 +333,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 			break;
 		if( hl >= stp.maxlen )
 			break;
-		if( rmd_paired( P, stp.pairset, rmd_code( sq, s5 + hl ), rmd_code( sq, s3 - hl ) ) )
+		if( ( ( mat2 >> ( rmd_code( sq, s5 + hl ) * 5 + rmd_code( sq, s3 - hl ) ) ) & 1u ) )
 			l_bpr = 1;
 		else{
 			mpr++;
@@ -466,7 +467,8 @@ RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const
 	if( stp.minlen == 0 )
 		return 1;
 	int	hl = 1, mpr = 0, l_bpr = 1;
-	if( !rmd_paired( P, stp.pairset, rmd_code( sq, s5 ), rmd_code( sq, s3 ) ) ){
+	const uint32_t	mat2 = rmd_pairsets( P )[ stp.pairset ].mat2;
+	if( !( ( mat2 >> ( rmd_code( sq, s5 ) * 5 + rmd_code( sq, s3 ) ) ) & 1u ) ){
 		if( stp.ends & RMA_5PAIRED )
 			return 0;
 		mpr = 1;
@@ -477,7 +479,7 @@ RMD_FN int rmd_quick_wchlx( const rmd_program_t *P, const rmd_elem_t &stp, const
 			return 1;
 		if( !( s3 - hl + 1 >= s3lim ) || hl >= stp.maxlen )
 			return 0;
-		if( rmd_paired( P, stp.pairset, rmd_code( sq, s5 + hl ), rmd_code( sq, s3 - hl ) ) )
+		if( ( mat2 >> ( rmd_code( sq, s5 + hl ) * 5 + rmd_code( sq, s3 - hl ) ) ) & 1u )
 			l_bpr = 1;
 		else{
 			if( ++mpr > stp.mplim )
@@ -879,7 +881,9 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 	rmd_lane_t *L, Sink &sink, const Accel &accel = Accel() )
 {
 	const int	d = P->searches[ k ];
-	const rmd_elem_t	&stp = P->elems[ d ];
+	// (a copy: the element's members are fetched together, at once, not one by one as the walk's branches ask for them --
+	// a step is a chain of dependent LDS reads, and a third of them were these)
+	const rmd_elem_t	stp = P->elems[ d ];
 	const int	is_ss = stp.type == RMA_T_SS;
 	const int	z = st.szero;
 	rmd_lrec_t	r = lr.get( k );
@@ -949,7 +953,7 @@ RMD_FN int rmd_lean_step( const rmd_program_t *P, LR &lr, rmd_lean_t &st, const 
 					c = rmd_lean_open( P, k + 1, c.zero, c.osd );
 					// look ahead: if the next level is a helix and none of its end
 					// positions can start it, this length of the ss leads nowhere
-					const rmd_elem_t	&nx = P->elems[ P->searches[ k + 1 ] ];
+					const rmd_elem_t	nx = P->elems[ P->searches[ k + 1 ] ];
 					if( nx.quick ){
 						const int	nlo = nx.loop ? c.zero + nx.minglen - 1 : c.osd;
 						for( ; ; ){
