@@ -715,6 +715,31 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 					break;
 				}
 			ch.on = any_leaf && ch.n > 0;
+			// Groups that are no stem-loops only shift and smear the vector of the group behind them: runs of them
+			// become one group (the sum of their length ranges), and a run in front of the first stem-loop goes into
+			// the range of the first element's own lengths -- a pass over the tile and a barrier less for each
+			// (trna.descr: eight passes -> five).
+			if( ch.on ){
+				rmd_chain_sib_t	m[ RMD_MAX_CHAIN ];
+				int	nm = 0;
+				for( int k = 0; k < ch.n; k++ ){
+					const rmd_chain_sib_t	&sb = ch.sib[ k ];
+					if( !sb.leaf && nm > 0 && !m[ nm - 1 ].leaf && int( m[ nm - 1 ].len_hi ) + sb.len_hi < 30000 ){
+						m[ nm - 1 ].len_lo = int16_t( m[ nm - 1 ].len_lo + sb.len_lo );
+						m[ nm - 1 ].len_hi = int16_t( m[ nm - 1 ].len_hi + sb.len_hi );
+					}else
+						m[ nm++ ] = sb;
+				}
+				int	first = 0;
+				if( nm > 1 && !m[ 0 ].leaf && int( ch.s_hi ) + m[ 0 ].len_hi < 30000 ){
+					ch.s_lo = int16_t( ch.s_lo + m[ 0 ].len_lo );
+					ch.s_hi = int16_t( ch.s_hi + m[ 0 ].len_hi );
+					first = 1;
+				}
+				ch.n = int8_t( nm - first );
+				for( int k = 0; k < ch.n; k++ )
+					ch.sib[ k ] = m[ first + k ];
+			}
 		}
 	}
 	for( int s = 0; s < p->n_sites; s++ ){
