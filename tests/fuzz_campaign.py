@@ -9,7 +9,10 @@ and a small work queue).  Run on the GPU box from the repository root:
 Round 1: 6400 lean, 5700 general and 3566 grouped descriptors, no mismatch.
 Round 3 (drain kernel, order words from the walk's choices, start positions by words): 1173 lean (seeds
 3000-4190), 1673 lean with everything through the drain kernel's list (RNAMOTIF_DBG=8388608, seeds
-9000-10698), 2482 general (3000-6000), 1106 grouped (3000-4121): no mismatch."""
+9000-10698), 2482 general (3000-6000), 1106 grouped (3000-4121): no mismatch.  And on the round's final build
+(walk that skips back over fixed single strands, merged chain passes, start positions by words in the general
+instances too): 1788 lean (20000-21821), 1751 lean through the list (30000-31796), 4943 general (6000-12000),
+404 grouped (9000-9407): no mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
