@@ -927,10 +927,14 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const bool	sv_on = ( LEAN && G == 1 && ( P->chain.on || P->lit_re >= 0 ) ) || ( !LEAN && P->lit_re >= 0 );
 	// (... and, last, where each base stands -- five vectors -- when there is a best literal to look for)
 	const int	n_vec = 1 + 5 * n_rs + ( !LEAN && ( KINDS & RMD_KIND_TQ ) != 0 && P->q1f.on ? ( P->q1f.t_on ? 9 : 4 ) : 0 ) + ( sv_on ? 1 : 0 ) +
-		( P->lit_re >= 0 ? 5 : 0 );
+		( P->lit_re >= 0 && G == 1 ? 5 : 0 );
 	unsigned long long	*const pb0 = reinterpret_cast<unsigned long long *>( tile0 + size_t( G ) * slot_bytes );
 	uint32_t	*lean_lo = reinterpret_cast<uint32_t *>( pb0 + size_t( G ) * n_vec * pb_words );
 	uint16_t	*lean_hi = reinterpret_cast<uint16_t *>( lean_lo + P->n_searches * BLOCK );
+	// (groups of small tiles: those five vectors live only from a slot's decode to its literal vector -- one set per
+	// wave, behind the records, not one per slot: sixteen sets cost ire.descr its tiles of 768 positions)
+	unsigned long long	*const lit_scratch = reinterpret_cast<unsigned long long *>(
+		( reinterpret_cast<uintptr_t>( lean_hi + P->n_searches * BLOCK ) + 7 ) & ~uintptr_t( 7 ) );
 	// the chain's working vectors -- where each base stands (5), two groups' vectors, a stem-loop's cores --
 	// take the place of the search records, which are not in use before pass B
 	unsigned long long	*const tv = reinterpret_cast<unsigned long long *>( lean_lo );
@@ -1044,6 +1048,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		slen = db.slen[ seq ];
 		tile = tile0 + size_t( slot ) * slot_bytes;
 		unsigned long long	*const occ = pb0 + size_t( slot ) * n_vec * pb_words;	// where the best literal occurs (bit per start)
+		unsigned long long	*const lvp = G > 1 ? lit_scratch + size_t( tid >> 6 ) * 5 * pb_words : occ + size_t( n_vec - 5 ) * pb_words;	// (only with a literal)
 		pb = occ + pb_words;		// row set 0
 		const int64_t	off = db.base_off[ seq ];
 		const int	local = live ? int( tt - db.tile_start[ seq ] ) : 0;
@@ -1135,7 +1140,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 						reinterpret_cast<uint32_t *>( tv + b5 * pb_words )[ dd ] = is[ b5 ];
 				if( P->lit_re >= 0 )
 					for( int b5 = 0; b5 < 5; b5++ )
-						reinterpret_cast<uint32_t *>( occ + ( n_vec - 5 + b5 ) * pb_words )[ dd ] = is[ b5 ];
+						reinterpret_cast<uint32_t *>( lvp + b5 * pb_words )[ dd ] = is[ b5 ];
 				if( q1f_vecs ){
 					// strand filter of a leading 4-plex (rmd_q1filter_t): where a base stands that some quad has in
 					// second / third place, and the same for the triples of a triplex that follows
@@ -1187,7 +1192,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		// entry have no bit in any vector.)
 		if( lit ){
 			const rmd_regex_t	&lre = rmd_regexes( P )[ P->lit_re ];
-			const unsigned long long	*const lv = occ + size_t( n_vec - 5 ) * pb_words;
+			const unsigned long long	*const lv = lvp;
 			for( int wi = utid; wi < vec_words; wi += UNIT ){
 				unsigned long long	acc = ~0ull;
 				for( int jj = 0; jj < lit_n; jj++ ){

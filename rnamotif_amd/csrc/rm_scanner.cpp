@@ -328,11 +328,13 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 	// borrow the place of the search records, which pass A does not use)
 	// (... and five when the descriptor has a best literal: where each base stands, for the literal's occurrence vector)
 	const size_t	pb_bytes = ( ( lean ? 6 + ( ( dp.chain.on || dp.lit_re >= 0 ) && group == 1 ? 1 : 0 ) : 1 + 5 * size_t( dp.n_rowsets ) + ( dp.q1f.on ? ( dp.q1f.t_on ? 9 : 4 ) : 0 ) + ( dp.lit_re >= 0 ? 1 : 0 ) ) +
-			( dp.lit_re >= 0 ? 5 : 0 ) ) *
+			( dp.lit_re >= 0 && group == 1 ? 5 : 0 ) ) *
 		( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;
+	if( lean && group > 1 && dp.lit_re >= 0 )	// (groups: the literal's five vectors once per wave, behind the records)
+		lds += 8 + size_t( SEARCH_BLOCK / 64 ) * 5 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	if( !lean && dp.split_s >= 0 )		// resume states of the levels up to the split level, queue of continuations
 		lds += size_t( dp.split_s + 1 ) * GENERAL_BLOCK * 8 + size_t( DEEP_QUEUE ) * ( 2 + 2 * ( dp.split_s + 1 ) ) * 4;
 	return lds;
