@@ -1048,8 +1048,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		slen = db.slen[ seq ];
 		tile = tile0 + size_t( slot ) * slot_bytes;
 		unsigned long long	*const occ = pb0 + size_t( slot ) * n_vec * pb_words;	// where the best literal occurs (bit per start)
-		unsigned long long	*const lvp = G > 1 ? lit_scratch + size_t( tid >> 6 ) * 5 * pb_words : occ + size_t( n_vec - 5 ) * pb_words;	// (only with a literal)
 		pb = occ + pb_words;		// row set 0
+		unsigned long long	*const xv_of_slot = pb + 5 * n_rs * pb_words;
+		unsigned long long	*const lvp = G > 1 ? lit_scratch + size_t( tid >> 6 ) * 6 * pb_words : occ + size_t( n_vec - 5 ) * pb_words;	// (only with a literal)
+		unsigned long long	*const lsv = G > 1 ? lvp + 5 * pb_words : xv_of_slot;		// where the literal's start positions go (G > 1: the wave's sixth vector)
 		const int64_t	off = db.base_off[ seq ];
 		const int	local = live ? int( tt - db.tile_start[ seq ] ) : 0;
 		const int	per_strand = live ? int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands ) : 1;
@@ -1479,7 +1481,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 			};
 			bool	by_words = false;
-			if constexpr( ( LEAN && G == 1 ) || !LEAN ){
+			{
 			bool	start_vec = chain;
 			const unsigned long long	*src = xv;		// the vector of start positions worth a look
 			if constexpr( !LEAN ){
@@ -1497,12 +1499,13 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					start_vec = true;
 				}
 			}
-			if( LEAN && !chain && lit && sv_on && !( dbg & 33554432 ) ){
+			if( LEAN && !chain && lit && ( G > 1 || sv_on ) && !( dbg & 33554432 ) ){
 				// no look-ahead chain, but a best literal: the start positions that have it within reach, as a vector
 				// (ire.descr, mp.ends.descr: one position in some hundred -- the same rounds saved)
-				for( int wi = tid; wi < vec_words; wi += BLOCK )
-					xv[ wi ] = lit_starts( wi * 64 );
-				__syncthreads();
+				for( int wi = utid; wi < vec_words; wi += UNIT )
+					lsv[ wi ] = lit_starts( wi * 64 );
+				SLOT_SYNC();
+				src = lsv;
 				start_vec = true;
 			}
 			if( start_vec ){
@@ -1745,19 +1748,19 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			}
 		}else{
 		bool	by_words = false;
-		if constexpr( LEAN && G == 1 ){
-		if( lit && sv_on && !quick && !split_ranks && !( dbg & 33554432 ) ){
+		if constexpr( LEAN ){
+		if( lit && ( G > 1 || sv_on ) && !quick && !split_ranks && !( dbg & 33554432 ) ){
 			// whole start positions are queued, and only those with the best literal within reach (ire.descr: one in
 			// 170): taken from the words of that vector, as above, not position by position
 			by_words = true;
-			for( int wi = tid; wi < vec_words; wi += BLOCK )
-				xv[ wi ] = lit_starts( wi * 64 );
-			__syncthreads();
+			for( int wi = utid; wi < vec_words; wi += UNIT )
+				lsv[ wi ] = lit_starts( wi * 64 );
+			SLOT_SYNC();
 			for( int q0 = 0; q0 < n_pos; q0 += UNIT * 16 ){
 				const int	rel_lo = q0 + utid * 16;
 				unsigned	m = 0;
 				if( rel_lo < n_pos ){
-					m = unsigned( bits64( xv, z0 + rel_lo - p_lo + 64 ) ) & 0xffffu;
+					m = unsigned( bits64( lsv, z0 + rel_lo - p_lo + 64 ) ) & 0xffffu;
 					if( n_pos - rel_lo < 16 )
 						m &= ( 1u << ( n_pos - rel_lo ) ) - 1u;
 				}

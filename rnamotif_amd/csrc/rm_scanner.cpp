@@ -334,7 +334,7 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
 	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;
 	if( lean && group > 1 && dp.lit_re >= 0 )	// (groups: the literal's five vectors once per wave, behind the records)
-		lds += 8 + size_t( SEARCH_BLOCK / 64 ) * 5 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+		lds += 8 + size_t( SEARCH_BLOCK / 64 ) * 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );	// (the sixth: the literal's start positions)
 	if( !lean && dp.split_s >= 0 )		// resume states of the levels up to the split level, queue of continuations
 		lds += size_t( dp.split_s + 1 ) * GENERAL_BLOCK * 8 + size_t( DEEP_QUEUE ) * ( 2 + 2 * ( dp.split_s + 1 ) ) * 4;
 	return lds;
