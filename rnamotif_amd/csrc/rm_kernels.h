@@ -50,14 +50,16 @@ struct HitBuf {
 #define SEARCH_WAVES_PER_SIMD	4
 #endif
 #ifndef GENERAL_WAVES_PER_SIMD
-#define GENERAL_WAVES_PER_SIMD	4
+#define GENERAL_WAVES_PER_SIMD	3
 #endif
 #ifndef RMD_KIND_PK
 #define RMD_KIND_PK	1	// improper (pseudoknot) helices
 #define RMD_KIND_TQ	2	// parallel helices, triplexes, 4-plexes
 #endif
 // (... three with 168 registers for descriptors with triplexes / 4-plexes: qu+tr 46.4 -> 39.2 ms, where
-// pk1 goes 7.5 -> 8.6 ms)
+// pk1 went 7.5 -> 8.6 ms in round 2, with workgroups of four waves.  With workgroups of one wave three and four
+// measure alike -- pk1 3.61 / 3.63 ms, pk_j1+2 67.4 / 68.3 -- and three spill 7 registers where four spill 80:
+// the general instances' scratch traffic is what the fourth wave cost.)
 #define GENERAL_WAVES( kinds_ )	( ( ( kinds_ ) & RMD_KIND_TQ ) ? 3 : GENERAL_WAVES_PER_SIMD )
 #ifndef SHORT_GROUP
 #define SHORT_GROUP		16	// tiles per workgroup pass for databases of short entries
