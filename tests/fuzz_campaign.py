@@ -13,7 +13,8 @@ Round 3 (drain kernel, order words from the walk's choices, start positions by w
 (walk that skips back over fixed single strands, merged chain passes, start positions by words in the general
 instances too): 1788 lean (20000-21821), 1751 lean through the list (30000-31796), 4943 general (6000-12000),
 404 grouped (9000-9407): no mismatch.  After the groups got the word-wise start positions: 2386 grouped
-(15000-17447) and 518 lean (40000-40524): no mismatch."""
+(15000-17447) and 518 lean (40000-40524): no mismatch.  General instances at three waves per SIMD: 3987 general
+(12000-16796): no mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
