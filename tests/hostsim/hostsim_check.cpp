@@ -131,8 +131,35 @@ static void sim_item( const rmd_program_t *dp, rmd_lane_t *lane, const rmd_seq_t
 		ArrRecs	recs;
 		rmd_lean_t	st;
 		int	k = rmd_lean_begin( dp, recs, st, szero, slen, r0, cnt );
-		while( k >= 0 )
+		// (the kernels' order words, where the descriptor allows them -- rmd_elem_t::ord_stride: the number of the walk's
+		// choices -- must grow from one candidate of a (start, rank) to the next as this walk finds them; checked here,
+		// for every candidate, as wave_emit computes them from the records)
+		long long	last_key = -1;
+		int	last_rank = -1;
+		while( k >= 0 ){
+			const size_t	had = sink.out->size();
 			k = rmd_lean_step( dp, recs, st, sq, k, lane, sink );
+			if( dp->ord_ok && sink.out->size() > had ){
+				long long	key = 0;
+				for( int kk = 0; kk < dp->n_searches; kk++ ){
+					const rmd_lrec_t	r = recs.get( kk );
+					const rmd_elem_t	&stp = dp->elems[ dp->searches[ kk ] ];
+					const int	first = ( kk == 0 || !stp.loop ) ? int( r.sd ) + 1 : int( rmd_lean_open( dp, kk, r.zero, r.osd ).sd );
+					const long long	digit = ( long long )( first - ( int( r.sd ) + 1 ) ) * stp.ord_nlen + ( stp.type == RMA_T_SS ? 0 : int( r.hl ) - stp.minlen );
+					if( digit < 0 ){
+						fprintf( stderr, "hostsim: negative order digit at level %d (start %d)\n", kk, szero );
+						exit( 3 );
+					}
+					key += digit * stp.ord_stride;
+				}
+				if( key >= ( 1ll << 31 ) || ( st.rank == last_rank && key <= last_key ) ){
+					fprintf( stderr, "hostsim: order word %lld after %lld at start %d rank %d\n", key, last_key, szero, st.rank );
+					exit( 3 );
+				}
+				last_key = key;
+				last_rank = st.rank;
+			}
+		}
 	}else{
 		GenRecs	recs;
 		memset( &recs, 0x55, sizeof( recs ) );	// (windows are written before they are read: any garbage must do)
