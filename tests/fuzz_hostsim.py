@@ -5,7 +5,10 @@ the descriptor generators of tests/test_gpu_parity.py.
     python tests/fuzz_hostsim.py general 0 2000 [workers]
     python tests/fuzz_hostsim.py lean-as-general 0 2000    (lean descriptors through the general path)
 
-Needs tests/_build/hostsim_check (built by tests/test_hostsim.py)."""
+Needs tests/_build/hostsim_check (built by tests/test_hostsim.py).
+
+Round 3: `lean 0 1500` -- 1471 generated lean descriptors, each candidate's order word (the number of the walk's
+choices, as the kernels store it) checked to grow along the walk: no mismatch, no order word out of place."""
 import os
 import subprocess
 import sys
