@@ -1948,13 +1948,15 @@ std::unique_ptr<Descriptor> init_only( const Args &args )
 	return d;
 }
 
-std::unique_ptr<Descriptor> compile_descriptor( const Args &args )	// rnamot.c:49-98
+std::unique_ptr<Descriptor> compile_descriptor( const Args &args, const std::string *expanded )	// rnamot.c:49-98
 {
 	std::unique_ptr<Descriptor>	d( new Descriptor );
 	d->args = args;
 	init_globals( *d );
 	std::string	text;
-	if( args.have_dfname )
+	if( expanded != nullptr )
+		text = *expanded;		// (a second descriptor from the text of the first: the files are not read again)
+	else if( args.have_dfname )
 		text = preprocess( *d );
 	else{
 		FILE	*fp = fopen( args.xdfname.c_str(), "r" );
@@ -1966,7 +1968,8 @@ std::unique_ptr<Descriptor> compile_descriptor( const Args &args )	// rnamot.c:4
 			text.append( buf, n );
 		fclose( fp );
 	}
-	if( args.have_dfname && args.have_xdfname ){	// -xdfname keeps the expanded text
+	d->expanded = text;
+	if( expanded == nullptr && args.have_dfname && args.have_xdfname ){	// -xdfname keeps the expanded text
 		FILE	*fp = fopen( args.xdfname.c_str(), "w" );
 		if( fp == nullptr )
 			fail( "RM_preprocessor: can't write temp file '%s'.", args.xdfname.c_str() );

@@ -184,7 +184,7 @@ public:
 	{
 		for( int t = 0; t < threads; t++ ){
 			std::unique_ptr<Worker>	w( new Worker );
-			w->d = compile_descriptor( d.args );
+			w->d = compile_descriptor( d.args, &d.expanded );
 			w->d->score->linkscore();
 			w->d->stderr_text.clear();		// (said once, by the descriptor the program runs on)
 			w->rp.reset( new Replayer( *w->d, prog, out ) );
@@ -544,8 +544,15 @@ int run_search( Descriptor &d, const rma_program_t &prog, ScanBackend &be, FILE 
 		const unsigned	hw = std::thread::hardware_concurrency();
 		const int	threads = rt ? atoi( rt ) : int( std::max( 1u, std::min( 8u, hw / 2 ) ) );
 		std::string	why;
-		if( threads > 1 && d.score->hit_independent( &why ) )
-			par.reset( new ParallelReplayer( d, prog, out, threads ) );
+		if( threads > 1 && d.score->hit_independent( &why ) ){
+			// (a worker that cannot be set up is no reason to give up a search one thread can replay)
+			try{
+				par.reset( new ParallelReplayer( d, prog, out, threads ) );
+			}catch( const Error &e ){
+				par.reset();
+				why = std::string( "workers could not be set up: " ) + e.what();
+			}
+		}
 		if( getenv( "RNAMOTIF_TIMING" ) )
 			fprintf( stderr, "[timing] replay on %d thread(s)%s%s\n", par ? threads : 1, par || threads <= 1 ? "" : ": ", par || threads <= 1 ? "" : why.c_str() );
 		pl.reset( new Pipeline( be, rp, prog, st, par.get() ) );

@@ -168,6 +168,7 @@ struct Descriptor {
 	bool	error = false;
 	std::unique_ptr<ScoreVM>	score;
 	std::string	stderr_text;			// non-fatal diagnostics
+	std::string	expanded;			// the preprocessed text it was parsed from (compile_descriptor)
 
 	Descriptor();
 	~Descriptor();
@@ -251,7 +252,9 @@ std::string	preprocess( Descriptor &d );
 bool	parse_descriptor( Descriptor &d, const std::string &text );
 
 // run the whole front end the way main() does (rnamot.c:49-98)
-std::unique_ptr<Descriptor>	compile_descriptor( const Args &args );
+// expanded: the preprocessed text of a descriptor compiled before (Descriptor::expanded) -- the descriptor files,
+// which may be readable only once (a pipe), are not opened again and -xdfname's file is not rewritten
+std::unique_ptr<Descriptor>	compile_descriptor( const Args &args, const std::string *expanded = nullptr );
 
 const char	*strel_name( int type );		// RM_strel_name, dump.c:600
 // -s / -d / -h listings, RM_dump dump.c:34 (rm_dump.cpp)

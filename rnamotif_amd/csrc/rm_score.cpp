@@ -707,6 +707,10 @@ bool ScoreVM::hit_independent( std::string *why ) const
 		return base( a ) == base( b ) ? base( a ) + 50 : int( TY_TOP );
 	};
 	std::string	trouble;
+	// A variable that is undefined when MAIN starts gets its type from the first assignment of the whole run
+	// (do_sto, score.c:2234-2261), whichever hit and path that is; each replay worker would latch it from its own
+	// first hit.  So every assignment to such a variable, anywhere in MAIN, must store the same type.
+	std::vector<int>	latched( size_t( nv ), -1 );
 	auto merge = [&]( int pc, const State &s ){
 		if( pc < 0 || pc > int( pr.size() ) ){
 			trouble = "jump out of the program";
@@ -871,6 +875,14 @@ bool ScoreVM::hit_independent( std::string *why ) const
 			const int	v = tm1 / 1000 - 1;
 			k.pop_back();
 			int	&vt = s.vt[ size_t( v ) ];
+			if( vars[ size_t( v ) ]->type == T_UNDEF ){
+				if( top != T_INT && top != T_FLOAT && top != T_STRING )
+					return no( "type of variable '" + vars[ size_t( v ) ]->name + "' depends on which hit assigns it first" );
+				if( latched[ size_t( v ) ] < 0 )
+					latched[ size_t( v ) ] = top;
+				else if( latched[ size_t( v ) ] != top )
+					return no( "type of variable '" + vars[ size_t( v ) ]->name + "' depends on which hit assigns it first" );
+			}
 			if( vt == T_UNDEF ){
 				// the first assignment ever latches the type: every assignment must agree on it
 				if( top != T_INT && top != T_FLOAT && top != T_STRING )

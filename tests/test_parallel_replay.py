@@ -28,6 +28,10 @@ PROGRAMS = [
     ("stale_value", "score\n\tBEGIN { y = 0; }\n\t{ if( length( ss[2] ) == 4 ) y = 7; SCORE = y; y = 1; }\n", False),
     ("score_sometimes", "score\n\t{ if( length( ss[2] ) == 4 ) SCORE = 1; }\n", False),
     ("type_latch", "score\n\t{ if( length( ss[2] ) == 4 ) v = 1; else v = 2.5; SCORE = v; }\n", False),
+    # (SCORE itself typed by the branch taken, an explicit ACCEPT behind the join -- each worker would latch
+    # the type from its own first hit: '16' / '1' where one thread prints '16.000' / '1.500' or the other way round)
+    ("type_latch_score", "score\n\t{ n = length( ss[2] ); if( n > 4 ) SCORE = n * 2; else SCORE = 1.5; ACCEPT; }\n", False),
+    ("type_latch_seq", "score\n\t{ v = 1; v = 2.5; SCORE = v; }\n", False),
     ("end_reads", "score\n\t{ last = length( ss[2] ); SCORE = last; }\n\tEND { last = last + 1; }\n", False),
     ("hold", "score\n\t{ SCORE = length( ss[2] ); if( SCORE == 4 ){ HOLD best; } else ACCEPT; }\n\tEND { RELEASE best; }\n", False),
 ]
@@ -84,3 +88,26 @@ def test_reference_score_programs(built, workdir, small_db, name):
     four = _run(built, workdir, ["-descr", name, small_db], 4, timing=False)
     assert one.returncode == 0 and four.returncode == 0
     assert four.stdout == one.stdout and len(one.stdout) > 100
+
+
+def test_descriptor_that_can_be_read_once(built, small_db, tmp_path):
+    """The workers of the parallel replay are compiled from the text the first descriptor was parsed from: a
+    descriptor that comes through a pipe (-descr <(cat x.descr)) is read once."""
+    import threading
+    (tmp_path / "x.descr").write_text(MOTIF + PROGRAMS[0][1])
+    want = _run(built, str(tmp_path), ["-descr", "x.descr", small_db], 4)
+    assert want.returncode == 0
+    fifo = tmp_path / "d.fifo"
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write((tmp_path / "x.descr").read_bytes())
+    t = threading.Thread(target=feed)
+    t.start()
+    got = _run(built, str(tmp_path), ["-descr", "d.fifo", small_db], 4)
+    t.join()
+    assert got.returncode == 0, got.stderr.decode()[-2000:]
+    assert "replay on 4 thread(s)" in got.stderr.decode()
+    # (the header names the descriptor file: everything after it is the same)
+    assert got.stdout.split(b"\n", 3)[3:] == want.stdout.split(b"\n", 3)[3:] and got.stdout.count(b"\n>") > 200
