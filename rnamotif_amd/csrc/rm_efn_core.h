@@ -17,6 +17,9 @@
 #ifndef RMD_FN
 #define RMD_FN	static inline
 #endif
+#ifndef RMD_FN_MEMBER
+#define RMD_FN_MEMBER	inline
+#endif
 
 // offsets of the tables inside the flat int16 image
 enum {
@@ -245,6 +248,9 @@ template< class X > RMD_FN int rme_efn( const X &x )
 		int	open = int( ( stk_open >> sp ) & 1 );
 		int	fb = open ? 0 : fbp;
 		int	done = 0;
+		// (RM_efn returns EFN_INFINITY itself from a call that meets a "knot", efn.c:1218,1262: what the call had
+		// added up before that -- dangles, the helix' stacks -- is dropped, what its callers hold is not)
+		const int	e_call = e;
 		if( x.bp( i ) == -1 || x.bp( j ) == -1 ){
 			while( x.bp( i ) == -1 && x.bp( i + 1 ) == -1 ){
 				i++;
@@ -280,7 +286,7 @@ template< class X > RMD_FN int rme_efn( const X &x )
 		if( x.bp( i ) != j ){
 			int	k = x.bp( i ), kp = x.bp( j );
 			if( k >= kp || sp + 2 > RME_STK ){
-				e += RME_INF;		// "knot": cannot happen for nested helices
+				e = e_call + RME_INF;		// "knot": pairs by a pair set of the descriptor's own (efn_usestdbp = 0) can make one
 				continue;
 			}
 			int	cut;			// first interval ends at cut
@@ -333,7 +339,7 @@ template< class X > RMD_FN int rme_efn( const X &x )
 				}
 			}
 			if( bad ){
-				e += RME_INF;
+				e = e_call + RME_INF;
 				break;
 			}
 			if( sum == 0 ){

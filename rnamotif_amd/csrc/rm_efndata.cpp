@@ -4,6 +4,7 @@
 // end up in one flat rma_efndata_t that is copied to the device.
 #include "rm_host.h"
 #include "rm_efndata.h"
+#include "rm_efn_core.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -376,5 +377,46 @@ std::string find_efndata_dir( Descriptor &d )	// score.c:1584-1590
 		return cp;
 	return "";
 }
+
+// The tables as the energy kernel reads them (rm_efn_core.h: one flat int16 image, staged in LDS; the tetraloop
+// keys, 18 bits, apart).  Also what tests/hostsim hands the same core compiled for the host.
+void efn_tables16( const rma_efndata_t *ed, std::vector<int16_t> &t16, std::vector<int32_t> &tlkey )
+{
+	t16.assign( ( RME_N16 + 7 ) / 8 * 8, 0 );	// padded for 16-byte staging loads
+	tlkey.assign( 100, -1 );
+	auto put = [&]( int off, const int32_t *src, int n ){
+		for( int i = 0; i < n; i++ ){
+			int	v = src[ i ];
+			t16[ off + i ] = int16_t( v > 32767 ? 32767 : v < -32768 ? -32768 : v );
+		}
+	};
+	put( RME_INTER, ed->inter, 31 );
+	put( RME_BULGE, ed->bulge, 31 );
+	put( RME_HAIRPIN, ed->hairpin, 31 );
+	put( RME_DANGLE, &ed->dangle[ 0 ][ 0 ][ 0 ][ 0 ], 250 );
+	put( RME_POPPEN, ed->poppen, 5 );
+	put( RME_EPARAM, ed->eparam, 16 );
+	int32_t	misc[ 9 ] = { ed->maxpen, ed->auend, ed->gubonus, ed->cslope, ed->cint, ed->c3, ed->gail,
+		ed->ntriloops, ed->ntloops };
+	put( RME_MISC, misc, 9 );
+	for( int k = 0; k < 50; k++ ){
+		// a key that does not fit 15 bits can never equal a computed key's low part
+		// by accident: store -1 (no computed key is negative)
+		int	key = k < ed->ntriloops ? ed->triloops[ k ][ 0 ] : -1;
+		t16[ RME_TRIKEY + k ] = int16_t( key >= 0 && key <= 32767 ? key : -1 );
+		t16[ RME_TRIVAL + k ] = int16_t( k < ed->ntriloops ? ed->triloops[ k ][ 1 ] : 0 );
+	}
+	for( int k = 0; k < 100; k++ ){
+		tlkey[ k ] = k < ed->ntloops ? ed->tloops[ k ][ 0 ] : -1;
+		t16[ RME_TLVAL + k ] = int16_t( k < ed->ntloops ? ed->tloops[ k ][ 1 ] : 0 );
+	}
+	put( RME_STACK, &ed->stack[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
+	put( RME_TSTKH, &ed->tstkh[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
+	put( RME_TSTKI, &ed->tstki[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
+	put( RME_SINT2, &ed->sint2[ 0 ][ 0 ][ 0 ][ 0 ], 900 );
+	put( RME_ASINT, &ed->asint1x2[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 4500 );
+	put( RME_SINT4, &ed->sint4[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 22500 );
+}
+
 
 }	// namespace rma

@@ -31,6 +31,7 @@
 #define RMD_FN_MEMBER	inline
 #include "rm_kernels.h"
 #include "rm_efn_core.h"
+#include "rm_efndata.h"
 #include "rm_fasta.h"
 #include "rm_pack.h"
 #include "rm_hitsort.h"
@@ -259,44 +260,6 @@ extern "C" void rma_db_destroy( rma_db_t *db );
 extern "C" void rma_scanner_destroy( rma_scanner_t *sc );
 extern "C" int rma_scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, char *err, size_t errlen );
 
-static void build_tables16( const rma_efndata_t *ed, std::vector<int16_t> &t16, std::vector<int32_t> &tlkey )
-{
-	t16.assign( ( RME_N16 + 7 ) / 8 * 8, 0 );	// padded for 16-byte staging loads
-	tlkey.assign( 100, -1 );
-	auto put = [&]( int off, const int32_t *src, int n ){
-		for( int i = 0; i < n; i++ ){
-			int	v = src[ i ];
-			t16[ off + i ] = int16_t( v > 32767 ? 32767 : v < -32768 ? -32768 : v );
-		}
-	};
-	put( RME_INTER, ed->inter, 31 );
-	put( RME_BULGE, ed->bulge, 31 );
-	put( RME_HAIRPIN, ed->hairpin, 31 );
-	put( RME_DANGLE, &ed->dangle[ 0 ][ 0 ][ 0 ][ 0 ], 250 );
-	put( RME_POPPEN, ed->poppen, 5 );
-	put( RME_EPARAM, ed->eparam, 16 );
-	int32_t	misc[ 9 ] = { ed->maxpen, ed->auend, ed->gubonus, ed->cslope, ed->cint, ed->c3, ed->gail,
-		ed->ntriloops, ed->ntloops };
-	put( RME_MISC, misc, 9 );
-	for( int k = 0; k < 50; k++ ){
-		// a key that does not fit 15 bits can never equal a computed key's low part
-		// by accident: store -1 (no computed key is negative)
-		int	key = k < ed->ntriloops ? ed->triloops[ k ][ 0 ] : -1;
-		t16[ RME_TRIKEY + k ] = int16_t( key >= 0 && key <= 32767 ? key : -1 );
-		t16[ RME_TRIVAL + k ] = int16_t( k < ed->ntriloops ? ed->triloops[ k ][ 1 ] : 0 );
-	}
-	for( int k = 0; k < 100; k++ ){
-		tlkey[ k ] = k < ed->ntloops ? ed->tloops[ k ][ 0 ] : -1;
-		t16[ RME_TLVAL + k ] = int16_t( k < ed->ntloops ? ed->tloops[ k ][ 1 ] : 0 );
-	}
-	put( RME_STACK, &ed->stack[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
-	put( RME_TSTKH, &ed->tstkh[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
-	put( RME_TSTKI, &ed->tstki[ 0 ][ 0 ][ 0 ][ 0 ], 625 );
-	put( RME_SINT2, &ed->sint2[ 0 ][ 0 ][ 0 ][ 0 ], 900 );
-	put( RME_ASINT, &ed->asint1x2[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 4500 );
-	put( RME_SINT4, &ed->sint4[ 0 ][ 0 ][ 0 ][ 0 ][ 0 ][ 0 ], 22500 );
-}
-
 extern "C" int rma_device_count( void )
 {
 	int	n = 0;
@@ -398,7 +361,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	if( efn != nullptr ){
 		std::vector<int16_t>	t16;
 		std::vector<int32_t>	tlkey;
-		build_tables16( efn, t16, tlkey );
+		rma::efn_tables16( efn, t16, tlkey );
 		HIPCHK( hipMalloc( &sc->d_t16, t16.size() * sizeof( int16_t ) ) );
 		HIPCHK( hipMemcpy( sc->d_t16, t16.data(), t16.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
 		HIPCHK( hipMalloc( &sc->d_tlkey, tlkey.size() * sizeof( int32_t ) ) );

@@ -19,7 +19,9 @@
 // every loop of the generators stop and resume)
 static int	hostsim_budget = 0;
 #include "rm_scan_core.h"
+#include "rm_efn_core.h"
 #include "rm_efn2_core.h"
+#include "rm_efndata.h"
 
 // strand view for the energy cores: code( p ) of the strand the hit lies on
 struct HostSeq {
@@ -278,7 +280,13 @@ int main( int argc, char **argv )
 		if( hostsim_budget > 0 )
 			dp.step_budget = hostsim_budget;
 		int	stride = dp.hit_stride, n_cmp = rma_hit_efn_off( pr.prog.get() );
-		int64_t	total = 0, bad = 0, n_efn2 = 0;
+		int64_t	total = 0, bad = 0, n_efn2 = 0, n_efn = 0;
+		// efn()'s tables as the energy kernel gets them (rma::efn_tables16)
+		std::vector<int16_t>	t16;
+		std::vector<int32_t>	tlkey;
+		if( pr.efn )
+			rma::efn_tables16( pr.efn.get(), t16, tlkey );
+		const rme_tables_t	T16{ t16.data(), tlkey.data(), pr.efn ? pr.efn->loginc : nullptr };
 		int	seq = 0;
 		for( const std::string &fn : args.dbfnames ){
 			FILE	*fp = fopen( fn.c_str(), "r" );
@@ -295,7 +303,7 @@ int main( int argc, char **argv )
 					rmo_hits_t	oh;
 					rmo_hits_init( &oh, pr.prog.get() );
 					rmo_set_efn2data( pr.efn2.get() );
-					rmo_scan( pr.prog.get(), nullptr, seq, buf.data(), slen, comp, &oh );
+					rmo_scan( pr.prog.get(), pr.efn.get(), seq, buf.data(), slen, comp, &oh );
 					std::vector<int32_t>	sh;
 					sim_scan( &dp, seq, buf.data(), slen, comp, sh );
 					int64_t	ns = int64_t( sh.size() ) / stride;
@@ -316,6 +324,27 @@ int main( int argc, char **argv )
 							}
 							bad++;
 							break;
+						}
+						// efn() sites: rm_efn_core.h compiled for the host, with the tables as the kernel has them,
+						// without and with the per-lane cache of base codes and partners
+						for( int k = 0; pr.efn && k < dp.n_efn; k++ ){
+							if( dp.efn_sites[ k ].kind == RMA_EFN_KIND_EFN2 )
+								continue;
+							HostSeq	hs{ buf.data() };
+							int16_t	bpbuf[ 97 ];
+							uint8_t	bcbuf[ 100 ];
+							const int	got = rme_site_energy( &dp, &T16, &hs, sh.data() + h * stride, k );
+							const int	got_c = rme_site_energy( &dp, &T16, &hs, sh.data() + h * stride, k, bpbuf, bcbuf, 96 );
+							const int	want = oh.data[ h * stride + n_cmp + k ];
+							n_efn++;
+							if( got != want || got_c != want ){
+								if( bad < 10 ){
+									fprintf( stderr, "seq %d comp %d hit %lld efn site %d: oracle %d, device core %d, with cache %d\n  record:", seq, comp, ( long long )h, k, want, got, got_c );
+									for( int q = 0; q < n_cmp; q++ ) fprintf( stderr, " %d", oh.data[ h * stride + q ] );
+									fprintf( stderr, "\n" );
+								}
+								bad++;
+							}
 						}
 						// efn2() sites: the device core, compiled for the host, against the oracle's value
 						for( int k = 0; pr.efn2 && k < dp.n_efn; k++ ){
@@ -344,6 +373,8 @@ int main( int argc, char **argv )
 		printf( "%s: %lld candidates, %lld mismatching strands", args.dfname.c_str(), ( long long )total, ( long long )bad );
 		if( n_efn2 > 0 )
 			printf( " (%lld efn2 energies compared)", ( long long )n_efn2 );
+		if( n_efn > 0 )
+			printf( " (%lld efn energies compared)", ( long long )n_efn );
 		printf( "\n" );
 		return bad ? 1 : 0;
 	}catch( rma::Error &e ){

@@ -344,6 +344,30 @@ def test_full_size_properties(built, workdir, name):
     assert np.array_equal(mirror, whole)
 
 
+@pytest.mark.parametrize("name", ["trna.efn.descr", "pk1.descr", "qu+tr.descr", "mp.ends.descr", "ire.descr"])
+def test_full_size_records_equal_oracle(built, workdir, name):
+    """BASELINE.json's configs at their own size -- 100 records of 1 Mbase, the bench workload -- against the
+    oracle over the WHOLE database, every start position of both strands (RM_find_motif's loop,
+    find_motif.c:164-207), not a sample: the records of the HIP scan equal the oracle's bit for bit, energies
+    included.  The oracle runs one process per host core, a record each (tests/oracle_pool.py); the bench line's
+    candidate counts (trna 5 837, pk1 10 400, qu+tr 1 037) are pinned here."""
+    import rnamotif_amd as R
+    from oracle_pool import concat_records, oracle_records
+    d = _descr(workdir, name)
+    records = list(range(100))
+    want_by_rec, info = oracle_records(["-descr", name], records, cwd=workdir)
+    want = concat_records(want_by_rec, records, d.hit_stride)
+    seqs = R.synthetic_records(100)
+    sc = R.Scanner(d)
+    got = sc.scan(sc.database(seqs))
+    print(f"{name}: {got.shape[0]} candidates; oracle {info['cpu_s']:.0f} core-seconds on {info['procs']} processes, wall {info['wall_s']:.1f} s")
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(got, want)
+    expected = {"trna.efn.descr": 5837, "pk1.descr": 10400, "qu+tr.descr": 1037}
+    if name in expected:
+        assert got.shape[0] == expected[name]
+
+
 def test_full_size_mixed_batch_on_one_database(built, workdir):
     """BASELINE config 5's single-GPU form: qu+tr.descr and mp.ends.descr over ONE upload of the 100
     Mbase database (a database belongs to a device, not to a descriptor), their kernels side by
@@ -382,7 +406,8 @@ def test_full_size_mixed_batch_on_one_database(built, workdir):
 def test_one_gbase_is_the_sum_of_its_slices(built, workdir):
     """The north star's size -- trna.descr over 1000 records of 1 Mbase on one GPU, the figure
     bench.py reports as north_star_1gbase: its records are the ten 100-record slices' records, one
-    after the other (the first slice is the headline workload), sorted, no duplicates."""
+    after the other (the first slice is the headline workload), sorted, no duplicates; a hundred records
+    drawn across the slices equal the oracle.  Then BASELINE config 5 over the same gigabase in HBM."""
     import rnamotif_amd as R
     sys.path.insert(0, ROOT)
     from bench import synthetic_slice
@@ -404,10 +429,49 @@ def test_one_gbase_is_the_sum_of_its_slices(built, workdir):
         R.Pack.write(pk, recs)
         del recs
         pack = R.Pack(pk)
-    whole = sc.scan(sc.database_from_pack(pack))
+    big = sc.database_from_pack(pack)
+    whole = sc.scan(big)
     assert pack.bases == 1_000_000_000 and whole.shape[0] > 50_000
     _sorted_unique(whole)
     assert np.array_equal(np.concatenate(parts), whole)
+    # ... and a hundred of its records, ten from every slice, are the oracle's bit for bit
+    from oracle_pool import oracle_records
+    sample = sorted(100 * k + (7 * k + 10 * j + 3) % 100 for k in range(10) for j in range(10))
+    assert len(set(sample)) == 100
+    want, info = oracle_records(["-descr", "trna.efn.descr"], sample, cwd=workdir)
+    n_cmp = 0
+    for k in sample:
+        got_k = whole[whole[:, 0] == k].copy()
+        got_k[:, 0] = 0
+        assert got_k.shape == want[k].shape and np.array_equal(got_k, want[k]), k
+        n_cmp += got_k.shape[0]
+    assert n_cmp > 5000
+    # BASELINE config 5 at its own size on one GPU: qu+tr.descr and mp.ends.descr over the SAME upload of the
+    # gigabase, kernels side by side; equal to each descriptor's ten slices, and fifty records each to the oracle
+    names = ("qu+tr.descr", "mp.ends.descr")
+    ds = [_descr(workdir, n) for n in names]
+    scs = [R.Scanner(dd) for dd in ds]
+    for s_ in scs:
+        s_.attach(big)
+    for s_ in scs:
+        s_.scan_begin(big)
+    together = [s_.scan_end() for s_ in scs]
+    big.close()
+    sample5 = sample[::2]
+    for n, dd, s_, got in zip(names, ds, scs, together):
+        _sorted_unique(got)
+        assert got.shape[0] > 1000
+        sl = []
+        for k in range(10):
+            h = s_.scan(s_.database(synthetic_slice(100 * k, 100, 1_000_000)))
+            h[:, 0] += 100 * k
+            sl.append(h)
+        assert np.array_equal(np.concatenate(sl), got), n
+        want5, _ = oracle_records(["-descr", n], sample5, cwd=workdir)
+        for k in sample5:
+            got_k = got[got[:, 0] == k].copy()
+            got_k[:, 0] = 0
+            assert got_k.shape == want5[k].shape and np.array_equal(got_k, want5[k]), (n, k)
 
 
 def test_start_position_ranges(built, workdir):
@@ -445,23 +509,37 @@ def test_mrnamotif_single_rank_equals_cli(built, workdir, gbrna, tmp_path):
     assert b"complete descr length: min/max = 63/95" in p.stderr
 
 
-@pytest.mark.parametrize("name", ["trna.efn2.descr", "hairpin.efn2.descr"])
+@pytest.mark.parametrize("name", ["trna.efn2.descr", "hairpin.efn2.descr", "hairpin.nostdbp.descr"])
 def test_efn2_sites_equal_oracle(built, workdir, gbrna, name):
     """efn2() on the device (rm_efn2_core.h: coaxial stacking, 1x1/2x1/2x2 interior loops from
-    global tables) beside efn(): every record, energies included, equals the oracle's."""
+    global tables) beside efn(): every record, energies included, equals the oracle's.
+    hairpin.nostdbp.descr: efn_usestdbp = 0 -- both functions pair the bases by the helix' own pair set, one
+    with g:a in it (setbp, score.c:3245; rm_efn_core.h rme_setup): half the records' energies change."""
     import rnamotif_amd as R
     from oracle_binding import oracle_scan
     d = R.Descriptor(["-descr", os.path.join(ROOT, "tests", "data", name)])
     assert d.efn2data
     recs = R.read_fasta(gbrna)
-    seqs = [r[2] for r in recs][:4067 if name.startswith("trna") else 400]
+    seqs = [r[2] for r in recs][:4067 if name.startswith("trna") else 60 if "nostdbp" in name else 400]
     sc = R.Scanner(d)
     got = sc.scan(sc.database(seqs))
     want = oracle_scan(d, seqs)
     assert want.shape[0] > 1000
     assert got.shape == want.shape and np.array_equal(got, want)
     e2 = got[:, d.efn_off]
-    assert np.all(np.abs(e2) < 100000)          # closed structures: always defined
+    if "nostdbp" in name:
+        # the switch matters: with the standard pairs the same candidates get other energies
+        text = open(os.path.join(ROOT, "tests", "data", name)).read().replace("efn_usestdbp = 0", "efn_usestdbp = 1")
+        with tempfile.TemporaryDirectory() as tmp:
+            open(os.path.join(tmp, "std.descr"), "w").write(text)
+            d1 = R.Descriptor(["-descr", os.path.join(tmp, "std.descr")])
+        sc1 = R.Scanner(d1)
+        std = sc1.scan(sc1.database(seqs))
+        assert std.shape == got.shape and np.array_equal(std[:, :d.efn_off], got[:, :d.efn_off])
+        assert np.array_equal(std, oracle_scan(d1, seqs))
+        assert (std[:, d.efn_off:] != got[:, d.efn_off:]).any(axis=1).mean() > 0.2
+    else:
+        assert np.all(np.abs(e2) < 100000)          # closed structures: always defined
 
 
 def test_cli_efn2_equals_oracle_cli(built, workdir):

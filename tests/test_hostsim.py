@@ -19,7 +19,7 @@ def hostsim():
                                           "rm_efndata.cpp", "rm_efn2data.cpp", "rm_fasta.cpp", "rm_driver.cpp", "rm_cli.cpp", "rm_dump.cpp", "rm_pack.cpp", "rm_stream.cpp",
                                           "rm_dev_program.cpp")]
     srcs += [os.path.join(ROOT, "oracle", f) for f in ("rm_oracle_scan.c", "rm_oracle_efn.c", "rm_oracle_efn2.c")]
-    newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(H, "rm_scan_core.h")])
+    newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(H, f) for f in ("rm_scan_core.h", "rm_efn_core.h", "rm_efn2_core.h", "rm_dev_program.h")])
     if not os.path.exists(BIN) or os.path.getmtime(BIN) < newest:
         subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + H,
                         "-I" + os.path.join(ROOT, "oracle"), "-o", BIN] + srcs + ["-lm"], check=True)
@@ -51,6 +51,26 @@ def test_efn2_device_core_equals_oracle(hostsim, workdir):
                        stderr=subprocess.PIPE, timeout=1800)
     assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
     assert b"1351 candidates, 0 mismatching strands (1351 efn2 energies compared)" in p.stdout
+
+
+def test_efn_device_core_equals_oracle(hostsim, workdir, gbrna, tmp_path):
+    """rm_efn_core.h compiled for the host, reading the tables as the kernel gets them (rma::efn_tables16), with and
+    without the per-lane cache of codes and partners: efn() of every cloverleaf candidate, and of hairpins paired
+    by the descriptor's own pair set (efn_usestdbp = 0, g:a pairs: RM_efn's "knot" returns, efn.c:1218,1262, drop
+    what the call had added up -- round 4 found the device core keeping it)."""
+    env = dict(os.environ, EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    p = subprocess.run([hostsim, "-descr", "trna.efn.descr", "gbrna.111.0.fastn"], cwd=workdir, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1800)
+    assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
+    assert b"1351 candidates, 0 mismatching strands (1351 efn energies compared)" in p.stdout
+    small = tmp_path / "small.fastn"
+    with open(gbrna, "rb") as f:
+        small.write_bytes(b"".join(f.readlines()[:1500]))
+    descr = os.path.join(ROOT, "tests", "data", "hairpin.nostdbp.descr")
+    p = subprocess.run([hostsim, "-descr", descr, str(small)], cwd=workdir, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1800)
+    assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()
+    assert b" 0 mismatching strands" in p.stdout and b"efn energies compared" in p.stdout
 
 
 def test_generated_descriptors(hostsim, tmp_path):
