@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the scan path (BASELINE.json).
 
-One step = SURVEY.md section 8d's step: one pass of the hot path over one batch of synthetic
-database -- upload of the packed batch (0.375 B/base, from page-locked host memory, on the device's
-upload stream), search kernel over every start position of both strands, efn kernel over every
-candidate, ordering and copy back of the hit records.  The upload of step i+1 runs under the
-kernels of step i (two buffers in HBM, rma_db_create_packed_async + rma_scan of the C ABI), as in
-the command line program's pipeline; every step's bases cross PCIe inside the timed region.
+One step = one pass of the hot path over one batch of synthetic database that is in HBM when the timed
+region starts: search kernel over every start position of both strands (+ the drain kernel behind it), efn
+kernel over every candidate, ordering and copy back of the hit records.  (Round 4: until round 3 `value` was
+SURVEY.md section 8d's step, with the upload of the packed batch -- 0.375 B/base from page-locked host memory on
+the device's upload stream, under the kernels of the step before -- inside it; that PCIe-inclusive rate is now
+the `h2d_inclusive` leg, and `value` under --h2d.)
 
 Workload at N=1: descr/trna.descr (4-stem cloverleaf, bits()+efn() score) over the 100 Mbase
 synthetic FASTA of BASELINE.md (100 records x 1 Mbase, iid uniform acgt, numpy default_rng(20240601))
--- BASELINE config 2.  `value` is that, over exactly --steps steps, upload included.
+-- BASELINE config 2.  `value` is that, over exactly --steps steps.
 
 Next to it, on rank 0 at N=1 with the default workload (none of it inside the timed K steps):
-  resident         the same scan over a database that stays in HBM (no upload in the step)
+  h2d_inclusive    the same step with the upload of its batch inside
+  real_db          the reference's own test database x 44 (100 Mbase in 179 k short entries): trna / pk1 / mp.ends,
+                   kernel ms as short entries and as the same bases in long entries, candidates cross-checked
   sustained        the headline step repeated for at least a second
   north_star_1gbase  the north star's own size: trna.descr over 1 Gbase on one GPU, >= 1 s timed
   cli_end_to_end   the whole command line program (bin/rnamotif -descr trna.descr) over 1 Gbase from a
@@ -150,7 +152,10 @@ def cpu_baseline_all_cores(descr_path, seqs, bases_per_core):
     """The reference's own way to use more cores is one process per database file (mrnamotif); the
     same here: every host core scans its own slice of the database."""
     import multiprocessing as mp
-    cores = min(len(os.sched_getaffinity(0)), 16, len(seqs))
+    from oracle_pool import host_cores
+    # every core this process may use: the affinity mask, cut to the cgroup's CPU quota (a GPU box of this pool shows 256
+    # cores of its two EPYC 9575F and grants the job 16 of them, /sys/fs/cgroup/cpu.max)
+    cores = min(host_cores(), len(seqs))
     jobs = [(descr_path, seqs[k][:bases_per_core]) for k in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
@@ -159,6 +164,7 @@ def cpu_baseline_all_cores(descr_path, seqs, bases_per_core):
     busy = max(r[2] for r in res)
     total = sum(r[0] for r in res)
     return {"value": round(total / busy / 1e6, 4), "unit": "Mbases/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "host_cores_visible": len(os.sched_getaffinity(0)), "host_cores_granted": host_cores(),
             "sample": f"{cores} processes x first {bases_per_core} bases of records 0..{cores - 1}, both strands, "
                       f"{sum(r[1] for r in res)} candidates, slowest process {busy:.1f} s (wall {wall:.1f} s with start-up)"}
 
@@ -222,6 +228,55 @@ def cli_end_to_end(descr_path, seqs, tmp, threads_env=None):
     return out
 
 
+REAL_DB = os.path.join(ROOT, "tests", "golden", "test", "gbrna.111.0.fastn.gz")
+REAL_DB_COPIES = 44
+# candidates (before the score program) of one copy of the reference's test database: the oracle's counts, which
+# tests/test_gpu_parity.py::test_hit_records_equal_oracle and tests/test_hostsim.py hold the GPU records to
+REAL_DB_CANDIDATES = {"trna.descr": 1351, "mp.ends.descr": 580, "pk1.descr": 9385}
+
+
+def real_db_leg(dev_index, names=("trna.descr", "pk1.descr", "mp.ends.descr")):
+    """The reference's own test database (test/gbrna.111.0.fastn: GenBank RNA entries, 4 067 of them, 560 bases on average,
+    2.7 % n) 44 times over = 100 Mbase in 179 k SHORT entries -- what real RNA databases look like, and the filters'
+    hard case next to iid uniform sequence (tRNA and rRNA genes cluster the pre-filter's survivors).  Per descriptor:
+    kernel ms and Mbases/s over the entries as they are, over the same bases joined into 44 long entries, and the
+    candidates, which must be 44 times one copy's (= the oracle's count of one copy)."""
+    import numpy as np
+    import rnamotif_amd as R
+    recs = R.read_fasta(REAL_DB)
+    one = [r[2] for r in recs]
+    short = one * REAL_DB_COPIES
+    joined = b"".join(one)
+    long_ = [joined] * REAL_DB_COPIES
+    bases = sum(len(s) for s in short)
+    out = {"database": "tests/golden/test/gbrna.111.0.fastn x %d" % REAL_DB_COPIES, "entries": len(short), "bases": bases,
+           "mean_entry_bases": round(bases / len(short), 1), "descriptors": {}}
+    for name in names:
+        path = os.path.join(ROOT, "tests", "golden", "descr" if name == "trna.descr" else "test", name)
+        d = R.Descriptor(["-descr", path])
+        sc = R.Scanner(d, device=dev_index)
+        res = {}
+        n_one = sc.scan(sc.database(one), copy=False).shape[0]
+        for what, seqs in (("short_entries", short), ("long_entries", long_)):
+            db = sc.database(seqs)
+            sc.scan_device(db)
+            ms, n = [], 0
+            for _ in range(5):
+                n, s_ms, _e = sc.scan_device(db)
+                k = sc.last_kernel_ms()
+                ms.append(k[0] + k[1])
+            db.close()
+            res[what] = {"kernel_ms": round(float(np.mean(ms)), 3), "mbases_per_s": round(bases / (float(np.mean(ms)) * 1e-3) / 1e6, 1), "candidates": int(n)}
+        res["short_over_long"] = round(res["short_entries"]["kernel_ms"] / res["long_entries"]["kernel_ms"], 3)
+        res["candidates_one_copy"] = int(n_one)
+        res["candidates_one_copy_oracle"] = REAL_DB_CANDIDATES.get(name)
+        res["candidates_ok"] = bool(res["short_entries"]["candidates"] == REAL_DB_COPIES * n_one and
+                                    (REAL_DB_CANDIDATES.get(name) is None or REAL_DB_CANDIDATES[name] == n_one))
+        out["descriptors"][name] = res
+        sc.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,18 +291,23 @@ def main():
                     help="descriptor file; a comma separated list = mixed batch (every descriptor over the same database)")
     ap.add_argument("--cpu-bases", type=int, default=12_000_000, help="sample size of the CPU baseline (0 = skip it and the other extras)")
     ap.add_argument("--north-star-records", type=int, default=1000, help="records of the 1-GPU north star run and of the command line leg (0 = skip)")
-    ap.add_argument("--resident", action="store_true", help="no upload inside the step: the database stays in HBM (then `value` is the resident rate)")
+    ap.add_argument("--resident", action="store_true", help="(kept for old command lines: the database staying in HBM is the default since round 4)")
+    ap.add_argument("--h2d", action="store_true", help="every step uploads its batch (SURVEY.md 8d's step): then `value` is the PCIe-inclusive rate")
+    ap.add_argument("--no-real-db", action="store_true", help="skip the real_db leg")
     ap.add_argument("--gather", choices=("native", "torch"), default="native", help="N > 1: rma_gather_hits (RCCL behind the C ABI) or torch.distributed")
     ap.add_argument("--backend", default=os.environ.get("RNAMOTIF_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo: tests with several ranks on one GPU)")
     args = ap.parse_args()
+    # `value` is measured with the inputs already in HBM when the timed region starts (the round's measurement rule); the
+    # PCIe-inclusive step of SURVEY.md 8d stands beside it as `h2d_inclusive` (and is `value` only under --h2d)
+    args.resident = not args.h2d
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank_env = int(os.environ.get("RANK", "0"))
     if world_env > 1 and args.total_records == 0 and not args.weak:
         args.total_records = 1000           # BASELINE config 4 / 5: 1 Gbase divided among the ranks
     default_workload = (args.descr == ap.get_default("descr") and args.records == 100 and
-                        args.record_len == 1_000_000 and args.total_records == 0 and not args.resident)
+                        args.record_len == 1_000_000 and args.total_records == 0 and args.resident)
     extras = world_env == 1 and args.cpu_bases > 0 and "," not in args.descr
     strong = args.total_records > 0
     if strong:
@@ -435,6 +495,14 @@ def main():
         for s_ in scs:
             s_.set_option("dbg", 0)
 
+    # what RCCL itself says the job is (ncclCommCount of the native gather's communicator), and every rank's kernel time
+    rccl_ranks = native.comm_count() if native is not None else None
+    per_rank_kernel_ms = None
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        t[rank] = search_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_kernel_ms = [round(float(x), 3) for x in t.tolist()]
     out = None
     if rank == 0:
         bases_per_gpu = db.bases
@@ -473,6 +541,8 @@ def main():
             "unit": "Mbases/s",
             "hits_per_s": round(total_hits / (dt / args.steps), 2),
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
+            "per_rank_kernel_ms": per_rank_kernel_ms,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -486,7 +556,8 @@ def main():
                             + (f"{args.total_records} x {args.record_len} base synthetic records divided among the ranks" if strong else
                                f"{args.records} x {args.record_len} base synthetic records per GPU")
                             + f" (iid uniform acgt, numpy default_rng({SEED})), both strands; " + where,
-                "step": "SURVEY.md 8d: H2D of the packed batch + search + efn + ordering + D2H of the hits" if not args.resident else "resident scan",
+                "step": "SURVEY.md 8d: H2D of the packed batch + search + efn + ordering + D2H of the hits" if not args.resident else
+                        "search kernel (+ drain kernel) + efn kernel + ordering + D2H of the hit records; the packed database is in HBM when the timed region starts",
                 "bases_per_gpu": bases_per_gpu,
                 "total_bases": total_bases,
                 "candidates": total_hits,
@@ -570,6 +641,13 @@ def main():
         out["cpu_baseline"] = cpu_baseline(descr, seqs, args.cpu_bases)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         out["cpu_baseline_all_cores"] = cpu_all
+        if default_workload and not args.no_real_db:
+            state["cur"].close()
+            try:
+                out["real_db"] = real_db_leg(dev_index)
+            except Exception as e:      # noqa: BLE001 -- a leg of its own
+                out["real_db"] = {"error": str(e)[:300]}
+            state["cur"] = new_db(True)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -198,10 +198,32 @@ int	rma_comm_unique_id( uint8_t id[ RMA_COMM_ID_BYTES ], char *err, size_t errle
 int	rma_comm_create( const uint8_t id[ RMA_COMM_ID_BYTES ], int rank, int world, int device,
 		rma_comm_t **out, char *err, size_t errlen );
 void	rma_comm_destroy( rma_comm_t *comm );
+/* The collective calls rma_gather_hits() makes, as a table.  rma_comm_create() fills it with RCCL's
+ * (ncclAllGather of int64, ncclSend / ncclRecv of int32, ncclGroupStart / ncclGroupEnd, ncclCommCount); a caller
+ * with another transport of the same semantics -- MPI between nodes where mrnamotif.c has MPI_Send / MPI_Recv, or
+ * a test that makes a call fail -- hands its own to rma_comm_create_on().  Every call returns 0 or a code that
+ * error_string() puts into words; stream is the hipStream_t the buffers are valid on; buffers are in HBM. */
+typedef struct rma_transport {
+	int	( *all_gather )( void *ctx, const void *send, void *recv, size_t n_int64_per_rank, void *stream );
+	int	( *send )( void *ctx, const void *buf, size_t n_int32, int peer, void *stream );
+	int	( *recv )( void *ctx, void *buf, size_t n_int32, int peer, void *stream );
+	int	( *group_start )( void *ctx );
+	int	( *group_end )( void *ctx );
+	const char	*( *error_string )( void *ctx, int code );	/* may be null */
+	int	( *comm_count )( void *ctx, int *count );		/* may be null */
+	void	*ctx;
+} rma_transport_t;
+int	rma_comm_create_on( const rma_transport_t *transport, int rank, int world, int device,
+		rma_comm_t **out, char *err, size_t errlen );
+/* The number of ranks the transport itself reports (RCCL: ncclCommCount; a world of one: 1). */
+int	rma_comm_count( rma_comm_t *comm, int *count, char *err, size_t errlen );
 /* Collective.  Every rank has ended a scan of its shard with rma_scan_end_on_device() (or rma_scan_end:
  * the records are still in HBM).  global_index[ i ], i < n_index, is the number in the whole database
- * of entry i of this rank's shard: word 0 of the records is rewritten to it on the device.  An
- * all-gather of the counts (8 bytes per rank), then one grouped send/receive: on rank `root`,
+ * of entry i of this rank's shard: word 0 of the records is rewritten to it on the device (once per scan: a second
+ * gather of the same records leaves them).  An all-gather of the counts and of a flag per rank (16 bytes per rank: a
+ * rank that cannot take part -- records ordered on the host, no entry numbers -- says so there, and every rank
+ * returns an error instead of waiting), a second one only when the root's buffers have to grow (could they?), then one
+ * grouped send/receive, whose group is closed on every path: on rank `root`,
  * *hits / *n_hits are all records, rank by rank, each rank's part in the reference's order (when the
  * ranks hold consecutive runs of entries that is the whole job's order; otherwise rma_sort_hits()
  * merges); elsewhere *n_hits = 0.  counts, if not NULL, receives every rank's count on every rank.

@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
     L.rma_comm_unique_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.rma_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_comm_destroy.argtypes = [vp]
+    L.rma_comm_create_on.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rma_comm_count.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.rma_gather_hits.argtypes = [vp, vp, i32p, C.c_int32, C.c_int, C.POINTER(i32p), i64p, i64p, C.c_char_p, C.c_size_t]
     L.rma_db_create.argtypes = [vp, cpp, i32p, C.c_int32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.rma_db_destroy.argtypes = [vp]
@@ -261,6 +263,10 @@ class Scanner:
         err = C.create_string_buffer(_ERRLEN)
         _check(lib().rma_scanner_set_option(self._h, name.encode(), int(value), err, _ERRLEN), err)
 
+    def forget_last(self) -> None:
+        """The last scan's records are no longer there for Comm.gather (a round in which this rank has no entries)."""
+        self.set_option("forget_last", 1)
+
     def warmup(self) -> None:
         err = C.create_string_buffer(_ERRLEN)
         _check(lib().rma_scanner_warmup(self._h, err, _ERRLEN), err)
@@ -408,6 +414,13 @@ class Comm:
         _check(L.rma_gather_hits(self._h, scanner._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx), root,
                                  C.byref(hits), C.byref(n), counts, err, _ERRLEN), err)
         return scanner._records(hits, n.value, True), [int(c) for c in counts]
+
+    def count(self) -> int:
+        """The number of ranks the transport itself reports (RCCL: ncclCommCount)."""
+        n = C.c_int()
+        err = C.create_string_buffer(_ERRLEN)
+        _check(lib().rma_comm_count(self._h, C.byref(n), err, _ERRLEN), err)
+        return n.value
 
     def close(self) -> None:
         if self._h:

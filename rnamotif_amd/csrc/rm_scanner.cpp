@@ -237,6 +237,8 @@ struct rma_scanner {
 	// what the last scan left on the device, in order (rma_scan_end): for rma_gather_hits()
 	const int32_t	*d_last = nullptr;
 	int64_t	n_last = 0;
+	int	last_state = 0;			// (rma_scanner_last_state)
+	bool	last_relabelled = false;	// rma_gather_hits has put database-wide entry numbers into d_last's records
 };
 
 struct rma_db {
@@ -493,9 +495,16 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 	else if( n == "host_sort" ) o.host_sort = value;
 	else if( n == "timing" ) o.timing = value;
 	else if( n == "short" ) o.short_force = value;
-	else{
+	else if( n == "forget_last" ){
+		// (not a switch: the last scan's records are no longer there for rma_gather_hits() -- a rank whose share of a
+		// round is empty sends nothing, whatever the round before left)
+		sc->d_last = nullptr;
+		sc->n_last = 0;
+		sc->last_state = 0;
+		sc->last_relabelled = false;
+	}else{
 		snprintf( err, errlen, "rma_scanner_set_option: no option '%s' that can change after creation "
-			"(dbg, pool, pool_min, pool_refill, drain, glist, drain_waves, host_sort, timing, short)", n.c_str() );
+			"(dbg, pool, pool_min, pool_refill, drain, glist, drain_waves, host_sort, timing, short; forget_last)", n.c_str() );
 		return 1;
 	}
 	return 0;
@@ -1039,6 +1048,8 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	}
 	sc->d_last = nullptr;
 	sc->n_last = 0;
+	sc->last_state = 0;
+	sc->last_relabelled = false;
 	const Layout	*lay = layout_for( sc, db, err, errlen );
 	if( lay == nullptr )
 		return 1;
@@ -1276,8 +1287,10 @@ static int scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, b
 		return 1;
 	lap( "search" );
 	*n_hits = n;
+	sc->last_state = 1;		// (no records: nothing to be anywhere)
 	if( n == 0 )
 		return 0;
+	sc->last_state = 2;		// (until the ordered records are known to be in HBM)
 	if( launch_efn( sc, n, err, errlen ) )
 		return 1;
 	if( timing ){
@@ -1324,6 +1337,7 @@ static int scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, b
 		lap( "ordered" );
 		sc->d_last = sc->dsort.d_out;
 		sc->n_last = n;
+		sc->last_state = 1;
 		if( hits )
 			*hits = copy_back ? sc->h_raw : nullptr;
 		return 0;
@@ -1337,6 +1351,7 @@ static int scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, b
 		HIPCHK( hipStreamSynchronize( sc->stream ) );
 		sc->d_last = sc->d_hits;
 		sc->n_last = 1;
+		sc->last_state = 1;
 		if( hits )
 			*hits = copy_back ? sc->h_raw : nullptr;
 		return 0;
@@ -1361,7 +1376,10 @@ static int scan_end( rma_scanner_t *sc, const int32_t **hits, int64_t *n_hits, b
 		HIPCHK( hipStreamSynchronize( sc->stream ) );
 		sc->d_last = sc->d_hits;
 		sc->n_last = n;
+		sc->last_state = 1;
 	}
+	// (copy_back with the ordering on the host: the ordered records are on the host only, last_state stays 2 and
+	// rma_gather_hits() says so instead of sending nothing)
 	if( hits )
 		*hits = sc->h_sorted.data();
 	return 0;
@@ -1446,3 +1464,7 @@ int rma_scanner_device( const rma_scanner_t *sc ) { return sc->device; }
 hipStream_t rma_scanner_stream( const rma_scanner_t *sc ) { return sc->stream; }
 int rma_scanner_stride( const rma_scanner_t *sc ) { return sc->dprog.hit_stride; }
 void rma_scanner_last( const rma_scanner_t *sc, const int32_t **d_hits, int64_t *n ) { *d_hits = sc->d_last; *n = sc->n_last; }
+// where the last scan's ordered records are: 0 no scan has ended, 1 in HBM (d_last; also a scan without records), 2 on the host only
+int rma_scanner_last_state( const rma_scanner_t *sc ) { return sc->last_state; }
+bool rma_scanner_last_relabelled( const rma_scanner_t *sc ) { return sc->last_relabelled; }
+void rma_scanner_set_relabelled( rma_scanner_t *sc ) { sc->last_relabelled = true; }

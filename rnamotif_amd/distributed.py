@@ -98,6 +98,17 @@ def all_ok(ok: bool, device=None) -> bool:
     return bool(int(t.item()))
 
 
+def all_min(code: int, device=None) -> int:
+    """The least of the ranks' codes on every rank (one MIN all-reduce): all_ok() with more than two answers."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return code
+    t = torch.tensor([int(code)], dtype=torch.int32, device=device if device is not None else torch.device("cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 _send_cache = {}
 
 
@@ -182,6 +193,9 @@ class NativeGather:
     def gather(self, scanner, global_index: Sequence[int], root: int = 0):
         """(records on root -- rank by rank, each part in order -- else empty; counts per rank)"""
         return self.comm.gather(scanner, global_index, root)
+
+    def comm_count(self) -> int:
+        return self.comm.count()
 
     def close(self) -> None:
         self.comm.close()

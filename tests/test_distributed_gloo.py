@@ -159,7 +159,7 @@ def cpu_scan(descr, pack, entries, ranges, local_rank):
 mrnamotif._init_process_group = cpu_group
 mrnamotif._scan_shard = cpu_scan
 os.chdir(sys.argv[2])
-mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], out_path=sys.argv[4])
+sys.exit(mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], out_path=sys.argv[4]))
 '''
 
 
@@ -255,8 +255,7 @@ FAILING_WORKER = MRNAMOTIF_WORKER.replace('''mrnamotif._scan_shard = cpu_scan'''
         raise RuntimeError("no scanner on this rank")
     return cpu_scan(descr, pack, entries, ranges, local_rank)
 
-mrnamotif._scan_shard = failing_scan''').replace('''mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], out_path=sys.argv[4])''',
-                                                 '''sys.exit(mrnamotif.run(["-descr", "sprintf.descr", sys.argv[3]], out_path=sys.argv[4]))''')
+mrnamotif._scan_shard = failing_scan''')
 
 
 def test_a_failing_rank_ends_the_job_on_every_rank(built, workdir, gbrna, tmp_path):
@@ -294,3 +293,33 @@ def test_mrnamotif_reads_what_rnamotif_reads(built, workdir, gbrna, tmp_path):
         p = _torchrun(script, [ROOT, workdir, str(path), str(out)], tmp_path, env={"EFNDATA": env["EFNDATA"]})
         assert p.returncode == 0, p.stdout.decode()[-4000:]
         assert out.read_bytes() == want.stdout
+
+
+def test_mrnamotif_rounds_and_rank0_reads_what_it_prints(built, workdir, gbrna, tmp_path):
+    """Shares in several rounds (the next round's entries read while this one is scanned and gathered), every rank --
+    the first too -- reading its own entries only, and rank 0 at the end the entries that have hits: byte for byte
+    what the single-process program prints; the laps say who read what."""
+    import re
+    import rnamotif_amd as R
+    recs = R.read_fasta(gbrna)[:1500]
+    fa = tmp_path / "db.fastn"
+    fa.write_bytes(b"".join(b">" + s + b" " + d + b"\n" + q + b"\n" for s, d, q in recs))
+    env = dict(os.environ, OMP_NUM_THREADS="1", EFNDATA=os.path.join(ROOT, "rnamotif_amd", "efndata"))
+    want = subprocess.run([built["oracle_cli"], "-descr", "sprintf.descr", str(fa)], cwd=workdir, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert want.returncode == 0 and want.stdout.count(b"\n>") > 10
+    script = tmp_path / "worker.py"
+    script.write_text(MRNAMOTIF_WORKER)
+    out = tmp_path / "out.txt"
+    p = _torchrun(script, [ROOT, workdir, str(fa), str(out)], tmp_path,
+                  env={"EFNDATA": env["EFNDATA"], "RNAMOTIF_BATCH_BASES": "120000", "RNAMOTIF_TIMING": "1"})
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
+    assert out.read_bytes() == want.stdout
+    log = p.stdout.decode()
+    per_rank = {r: [int(m) for m in re.findall(r"\[timing\] rank %d read round \d+: (\d+) entries" % r, log)] for r in (0, 1)}
+    assert len(per_rank[0]) == len(per_rank[1]) >= 3                 # the same number of rounds on every rank
+    assert sum(per_rank[0]) + sum(per_rank[1]) == len(recs)            # every entry read once, by the rank that scans it
+    assert abs(sum(per_rank[0]) - sum(per_rank[1])) < len(recs) // 3   # (rank 0 reads its share, not the database)
+    with_hits = int(re.search(r"rank 0 read (\d+) entries with hits", log).group(1))
+    assert 0 < with_hits < len(recs)                                   # (entries with candidates: the score program rejects most)
+    assert "the whole database" not in log
