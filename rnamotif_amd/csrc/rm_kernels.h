@@ -15,9 +15,11 @@ struct DbView {
 	const int32_t	*slen;		// [n_seq]
 	const int64_t	*tile_start;	// [n_seq+1] prefix sum of tiles over sequences
 	const int32_t	*tile_seq;	// [n_tiles] sequence of every tile (saves a search per tile)
+	const int32_t	*tile_meta;	// [n_tiles][RMK_META_WORDS] one tile per workgroup pass: the tile's entry, strand, first start position ... in one line
 	const int32_t	*pos_lo, *pos_hi;	// [n_seq] or null: only start positions lo <= szero < hi (each strand)
 	int32_t	n_seq, strands, tile_t;
 	int64_t	n_tiles;
+	int64_t	concat_bases;		// > 0: the tiles lie over the concatenation of the entries, this many bases a strand (rm_scanner.cpp, Layout::concat)
 };
 
 struct HitBuf {
@@ -35,6 +37,9 @@ struct HitBuf {
 	// the items reserved in it (may exceed glist_cap), ticket[ RMK_GCTL ] those taken (rma_drain_kernel)
 	int	glist_cap;
 };
+
+// words of a tile's line in DbView::tile_meta
+enum { RMK_META_SEQ = 0, RMK_META_COMP, RMK_META_Z0, RMK_META_SLEN, RMK_META_OFF_LO, RMK_META_OFF_HI, RMK_META_POS_HI, RMK_META_PAD, RMK_META_WORDS };
 
 // ---------------------------------------------------------------- launch-shape constants
 #ifndef QCAP
@@ -86,6 +91,7 @@ struct HitBuf {
 // and the database's shape).
 enum rmk_instance {
 	RMK_LEAN_POOL = 0,	// lean, pass B over a pool of survivors (the headline instance)
+	RMK_LEAN_CONCAT,	// ... with the tiles over the concatenation of the entries (databases of short entries)
 	RMK_LEAN_GROUP,		// lean, groups of SHORT_GROUP small tiles (databases of short entries)
 	RMK_LEAN_TILE,		// lean, pass B tile by tile
 	RMK_GEN_PLAIN,		// general, no pseudoknot, no triplex / 4-plex
@@ -107,6 +113,7 @@ struct rmk_search_args {
 hipError_t	rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 // the launchers behind it, one translation unit each (rm_scan_inst_*.hip)
 hipError_t	rmk_launch_lean_pool( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_lean_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_drain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );	// (qcap: not used; tile_bytes: window dwords per lane)
 hipError_t	rmk_launch_lean_group( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_tile( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );

@@ -245,14 +245,70 @@ __device__ inline void wave_emit_pending( const rmd_program_t *P, const LdsRecs<
 	}
 }
 
+// Tiles over the concatenation of the entries (DbView::concat_bases > 0; databases of short entries): pass A works on a
+// strand of the whole packed array as if it were one long entry -- full vectors whatever the entries' lengths, and no
+// knowledge of where an entry ends: all its tests are necessary conditions on the bases between a start and an end
+// position, which for a true candidate lie in one entry.  What they let through is brought back to its entry here, when
+// it leaves the tile: start position szero_u and end rank r_u (0xffff: all) of the concatenation's strand comp -> the
+// entry, the start position within it and the rank among ITS end positions (rmd_level0_range with the entry's length);
+// false for a start in the padding between entries, too close to its entry's end for the motif, or an end position
+// beyond it.  k_lo, k_n: the entries the tile's start positions fall into (DbView::tile_meta).  start_u: where the
+// entry's strand begins in the concatenation's (the tile's) coordinates.
+__device__ inline bool super_convert( const rmd_program_t *P, const int64_t *base_off, const int32_t *slens, long long total, int comp, int k_lo, int k_n, int szero_u, int r_u,
+	int *seq, int *szero_e, int *r_e, int *start_u, int *slen_e )
+{
+	const int64_t	g = comp ? int64_t( total ) - 1 - szero_u : szero_u;	// the start position's base in the packed arrays
+	int	lo = k_lo, hi = k_lo + k_n;		// the last entry of [ lo, hi ) that begins at or before g
+	while( hi - lo > 1 ){
+		const int	mid = ( lo + hi ) >> 1;
+		if( base_off[ mid ] <= g )
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const int64_t	off = base_off[ lo ];
+	const int	sl = slens[ lo ];
+	if( g < off || g >= off + sl )
+		return false;
+	const int	sz = comp ? int( off + sl - 1 - g ) : int( g - off );
+	if( sz > sl - P->dminlen )
+		return false;
+	*start_u = szero_u - sz;
+	*r_e = 0xffff;
+	if( r_u != 0xffff ){
+		int	hi_u, lo_u, hi_e, lo_e;
+		rmd_level0_range( P, szero_u, int( total ), &hi_u, &lo_u );
+		rmd_level0_range( P, sz, sl, &hi_e, &lo_e );
+		const int	end_e = hi_u - r_u - *start_u;
+		if( end_e > hi_e || end_e < lo_e )
+			return false;
+		*r_e = hi_e - end_e;
+	}
+	*seq = lo;
+	*szero_e = sz;
+	*slen_e = sl;
+	return true;
+}
+
 // The lanes with `over` set search the item ( szero, r0, cnt ) each has got, start to end (what a tile's pass
 // A does with items that found room neither in the queue nor in its spill area; rare, kept out of line).
 // Called by all 64 lanes.
-template< int BLOCK >
-__device__ __noinline__ void lean_search_here( const rmd_program_t *P, uint32_t *lo, uint16_t *hi, const uint8_t *sq_bytes, int sq0,
-	bool over, int szero, int slen, int r0, int cnt, int seq, int comp, int32_t *hits, unsigned long long *count, long long cap, int lane_id )
+// cc: tiles over a concatenation of entries (super_convert) -- the item is brought to its entry's coordinates first, the tile's
+// bytes are seen from there (sq0, slen, seq then differ from lane to lane); cc.total == 0: not such a tiling.
+struct ConcatCtx { const int64_t *base_off; const int32_t *slens; long long total; int k_lo, k_n; };
+template< int BLOCK, bool CONCAT >
+__device__ __forceinline__ void lean_search_here_body( const rmd_program_t *P, uint32_t *lo, uint16_t *hi, const uint8_t *sq_bytes, int sq0,
+	bool over, int szero, int slen, int r0, int cnt, int seq, int comp, int32_t *hits, unsigned long long *count, long long cap, int lane_id,
+	const ConcatCtx cc )
 {
 	LdsRecs<BLOCK>	lr{ lo, hi };
+	if( CONCAT && over ){
+		int	st_u = 0, re = 0;
+		over = super_convert( P, cc.base_off, cc.slens, cc.total, comp, cc.k_lo, cc.k_n, szero, cnt == 1 ? r0 : 0xffff, &seq, &szero, &re, &st_u, &slen );
+		sq0 -= st_u;
+		if( cnt == 1 )
+			r0 = re;
+	}
 	const rmd_seq_t	sq{ sq_bytes, sq0 };
 	HitBuf	hb{};
 	hb.hits = hits;
@@ -266,8 +322,14 @@ __device__ __noinline__ void lean_search_here( const rmd_program_t *P, uint32_t 
 	while( __ballot( k >= 0 ) ){
 		if( k >= 0 )
 			k = rmd_lean_step<LdsRecs<BLOCK>, DevSink, rmd_seq_t, rmd_no_accel_t, true>( P, lr, st, sq, k, nullptr, sink );
-		wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int ){ return sq; }, seq, comp, hb, lane_id );
+		wave_emit_pending<BLOCK>( P, lr, st, k, [ & ]( int l ){ return rmd_seq_t{ sq_bytes, __shfl( sq0, l ) }; }, seq, comp, hb, lane_id );
 	}
+}
+template< int BLOCK >
+__device__ __noinline__ void lean_search_here( const rmd_program_t *P, uint32_t *lo, uint16_t *hi, const uint8_t *sq_bytes, int sq0,
+	bool over, int szero, int slen, int r0, int cnt, int seq, int comp, int32_t *hits, unsigned long long *count, long long cap, int lane_id )
+{
+	lean_search_here_body<BLOCK, false>( P, lo, hi, sq_bytes, sq0, over, szero, slen, r0, cnt, seq, comp, hits, count, cap, lane_id, ConcatCtx{} );
 }
 
 // General path records of one lane in LDS (rmd_grec_t, 12 bytes per level): three dwords at
@@ -860,12 +922,16 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 // pool_min have come together: a lane pops an item, rebuilds its window from the packed database
 // into a column of LDS (4 bits per base; the tile and its bit vectors are not needed then and lend
 // their place), walks it, and pops the next -- every lane busy until the pool runs dry.
-template< int BLOCK, bool LEAN, int G, int KINDS = 0, bool POOL = false >
+// CONCAT (pooled instance): the tiles lie over the concatenation of the entries (DbView::concat_bases, super_convert) -- an
+// instance of its own, so that the instance for databases of long entries is, to the register, what it was without it
+// (the headline kernel sits at its 128 registers: a dozen more live values in pass A' cost it a quarter of its speed).
+template< int BLOCK, bool LEAN, int G, int KINDS = 0, bool POOL = false, bool CONCAT = false >
 __global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES( KINDS ) )
 rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	static_assert( G == 1 || ( LEAN && G % ( BLOCK / 64 ) == 0 && G <= 32 ), "tile groups: lean path, whole rounds of waves" );
 	static_assert( !POOL || ( LEAN && G == 1 ), "pooled pass B: lean path, one tile per pass" );
+	static_assert( !CONCAT || POOL, "tiles over a concatenation of entries: the pooled instance" );
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
 	// gP is the compact image (rmd_make_image): prog_bytes of it, a multiple of 16
@@ -923,6 +989,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const bool	q1f = q1f_vecs && !( dbg & 8192 );
 	// (lean, one tile per pass, with a look-ahead chain: eight more, rmd_chain_t)
 	const bool	chain_on = LEAN && G == 1 && P->chain.on;
+	// (tiles over the concatenation of the entries: super_convert)
+	constexpr bool	concat = CONCAT;
 	// (a vector of the start positions worth a look: what the look-ahead chain leaves, or where the best literal is within reach)
 	const bool	sv_on = ( LEAN && G == 1 && ( P->chain.on || P->lit_re >= 0 ) ) || ( !LEAN && P->lit_re >= 0 );
 	// (... and, last, where each base stands -- five vectors -- when there is a best literal to look for)
@@ -997,20 +1065,40 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	const long long	n_units = G > 1 ? ( db.n_tiles + G - 1 ) / G : db.n_tiles;
 	// (the ticket of the tile after this one is asked for while this one is worked on: the one counter all
 	// workgroups share answers in microseconds, and nobody should wait for it with a tile in hand)
-	long long	t_next = 0;
-	if( tid == 0 )
+	// One tile per pass: the tickets run TWO tiles ahead, so that the tile's line of DbView::tile_meta -- entry, strand,
+	// first start position, length, place in the packed arrays: all the kernel asks of a tile -- is fetched a tile ahead,
+	// by two lanes, straight into LDS (no register holds it meanwhile), two buffers in turns.  Until round 4 a tile began
+	// with three dependent loads (tile_seq[ t ]; the entry's slen / base_off / tile_start; the packed words): the phase
+	// counters had 42 % of the headline kernel's wave cycles in its "decode" phase, most of it those round trips.
+	__shared__ __align__( 16 ) int	s_meta[ 2 ][ RMK_META_WORDS ];
+	__shared__ long long	s_tile_nx;
+	long long	t_next = 0, t_next2 = 0;
+	if( tid == 0 ){
 		t_next = ( long long )atomicAdd( hb.ticket, 1ull );
+		if constexpr( G == 1 ){
+			t_next2 = ( long long )atomicAdd( hb.ticket, 1ull );
+			if( t_next < db.n_tiles )
+				for( int k = 0; k < RMK_META_WORDS; k++ )
+					s_meta[ 0 ][ k ] = db.tile_meta[ t_next * RMK_META_WORDS + k ];
+		}
+	}
 	bool	had_tiles = false;
 	if( ( dbg & 1048576 ) && tid == 0 )
 		atomicMax( hb.ticket + 88, ~( unsigned long long )wall_clock64() );	// (the first workgroup's start)
-	for( ; ; ){
+	for( int pass = 0; ; pass++ ){
 		if( tid == 0 ){
 			const long long	t = t_next;
-			if( t < n_units )
-				t_next = ( long long )atomicAdd( hb.ticket, 1ull );
-			const int	s = G == 1 && t < db.n_tiles ? db.tile_seq[ t ] : 0;
+			if constexpr( G == 1 ){
+				t_next = t_next2;
+				if( t < n_units )
+					t_next2 = ( long long )atomicAdd( hb.ticket, 1ull );
+				s_tile_nx = t_next;
+			}else{
+				if( t < n_units )
+					t_next = ( long long )atomicAdd( hb.ticket, 1ull );
+			}
 			s_tile = t;
-			s_seq = s;
+			s_seq = 0;
 			s_qn = 0;
 			s_qhead = 0;
 			s_dqn = 0;
@@ -1018,6 +1106,13 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		}
 		__syncthreads();
 		const long long	t = s_tile;
+		if constexpr( G == 1 ){
+			// the next tile's line, on its way into the other buffer (read at the next pass, many barriers from here)
+			const long long	tn = s_tile_nx;
+			if( tn < db.n_tiles && tid < RMK_META_WORDS / 4 )
+				__builtin_amdgcn_global_load_lds( ( const __attribute__(( address_space( 1 ) )) void * )( db.tile_meta + tn * RMK_META_WORDS + tid * 4 ),
+					( __attribute__(( address_space( 3 ) )) void * )( &s_meta[ ( pass + 1 ) & 1 ][ 0 ] ), 16, 0, 0 );
+		}
 		bool	last = false;
 		if( t >= n_units ){
 			// (pooled: one more round, over a tile without start positions, for what the pool still holds)
@@ -1033,6 +1128,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			had_tiles = true;
 		// what pass B needs of the tile (G > 1: of the last slot; pass B reloads per item)
 		int	seq = 0, slen = 0, z0 = 0, p_lo = 0, vec_words = 0;
+		int	ent_n = 0;	// (tiles over a concatenation: the entries from `seq` on that the tile's start positions fall into)
 		uint8_t	*tile = tile0;
 		unsigned long long	*pb = pb0 + pb_words;
 		rmd_seq_t	sq{ tile0, 0 };
@@ -1044,21 +1140,37 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		const long long	tt = G > 1 ? t * G + slot : t;
 		const bool	live = tt < db.n_tiles;
 		const unsigned	slot_bits = G > 1 ? unsigned( slot ) << 26 : 0u;
-		seq = G > 1 ? ( live ? db.tile_seq[ tt ] : 0 ) : s_seq;
-		slen = db.slen[ seq ];
+		int64_t	off = 0;
+		int	comp = 0, pos_hi = 0x7fffffff;
+		if constexpr( G == 1 ){
+			// (the tile's line, fetched a pass ago)
+			const int	*const m = s_meta[ pass & 1 ];
+			ent_n = live ? m[ RMK_META_PAD ] : 0;
+			seq = live ? m[ RMK_META_SEQ ] : 0;
+			comp = live ? m[ RMK_META_COMP ] : 0;
+			z0 = live ? m[ RMK_META_Z0 ] : 0;
+			slen = live ? m[ RMK_META_SLEN ] : 0;
+			off = live ? int64_t( ( uint64_t( uint32_t( m[ RMK_META_OFF_HI ] ) ) << 32 ) | uint32_t( m[ RMK_META_OFF_LO ] ) ) : 0;
+			pos_hi = live ? m[ RMK_META_POS_HI ] : 0;
+		}else{
+			seq = live ? db.tile_seq[ tt ] : 0;
+			slen = db.slen[ seq ];
+		}
 		tile = tile0 + size_t( slot ) * slot_bytes;
 		unsigned long long	*const occ = pb0 + size_t( slot ) * n_vec * pb_words;	// where the best literal occurs (bit per start)
 		pb = occ + pb_words;		// row set 0
 		unsigned long long	*const xv_of_slot = pb + 5 * n_rs * pb_words;
 		unsigned long long	*const lvp = G > 1 ? lit_scratch + size_t( tid >> 6 ) * 6 * pb_words : occ + size_t( n_vec - 5 ) * pb_words;	// (only with a literal)
 		unsigned long long	*const lsv = G > 1 ? lvp + 5 * pb_words : xv_of_slot;		// where the literal's start positions go (G > 1: the wave's sixth vector)
-		const int64_t	off = db.base_off[ seq ];
-		const int	local = live ? int( tt - db.tile_start[ seq ] ) : 0;
-		const int	per_strand = live ? int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands ) : 1;
-		const int	comp = local / per_strand;
-		const int	pos_lo = db.pos_lo ? db.pos_lo[ seq ] : 0;
-		const int	pos_hi = db.pos_hi ? db.pos_hi[ seq ] : 0x7fffffff;
-		z0 = pos_lo + ( local % per_strand ) * T;
+		if constexpr( G > 1 ){
+			off = db.base_off[ seq ];
+			const int	local = live ? int( tt - db.tile_start[ seq ] ) : 0;
+			const int	per_strand = live ? int( ( db.tile_start[ seq + 1 ] - db.tile_start[ seq ] ) / db.strands ) : 1;
+			comp = local / per_strand;
+			const int	pos_lo = db.pos_lo ? db.pos_lo[ seq ] : 0;
+			pos_hi = db.pos_hi ? db.pos_hi[ seq ] : 0x7fffffff;
+			z0 = pos_lo + ( local % per_strand ) * T;
+		}
 
 		// decode the bases this tile can touch: [ z0 - lm, z0 + T + w - 1 + rm )
 		p_lo = z0 - lm;
@@ -1273,7 +1385,18 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				if( __ballot( over_ ) ){ \
 					/* items beyond the queue and its spill area are searched here and now */ \
 					s_inplace = 1; \
-					lean_search_here<BLOCK>( P, lr.lo, lr.hi, sq.sq, sq.sq0, over_, szero_, slen, r0_, cnt_, sink.seq, sink.comp, hb.hits, hb.count, hb.cap, lane_id ); \
+					if constexpr( CONCAT ){ \
+						/* (tiles over a concatenation: the item in its entry's coordinates, the tile's bytes seen from there) */ \
+						int	o_sq0_ = sq.sq0, o_sz_ = szero_, o_sl_ = slen, o_r_ = r0_, o_seq_ = sink.seq; \
+						if( over_ ){ \
+							int	st_u_ = 0, re_ = 0; \
+							over_ = super_convert( P, db.base_off, db.slen, db.concat_bases, sink.comp, seq, ent_n, szero_, ( cnt_ ) == 1 ? ( r0_ ) : 0xffff, &o_seq_, &o_sz_, &re_, &st_u_, &o_sl_ ); \
+							o_sq0_ = sq.sq0 - st_u_; \
+							o_r_ = ( cnt_ ) == 1 ? re_ : ( r0_ ); \
+						} \
+						lean_search_here<BLOCK>( P, lr.lo, lr.hi, sq.sq, o_sq0_, over_, o_sz_, o_sl_, o_r_, cnt_, o_seq_, sink.comp, hb.hits, hb.count, hb.cap, lane_id ); \
+					}else \
+						lean_search_here<BLOCK>( P, lr.lo, lr.hi, sq.sq, sq.sq0, over_, szero_, slen, r0_, cnt_, sink.seq, sink.comp, hb.hits, hb.count, hb.cap, lane_id ); \
 				} \
 			} \
 		} }while( 0 )
@@ -1932,6 +2055,14 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 							// (a length that failed its tests keeps the mask 0: the walk finds nothing there either way)
 						}
 					}
+					// what the pool holds of an item: its entry, its start position there, its rank among the end positions
+					int	p_seq = seq, p_szero = z0 + int( item >> 16 ), p_r = int( item & 0xffffu );
+					if constexpr( CONCAT ){
+						if( keep ){
+							int	st_u_, sl_;
+							keep = super_convert( P, db.base_off, db.slen, db.concat_bases, sink.comp, seq, ent_n, p_szero, p_r, &p_seq, &p_szero, &p_r, &st_u_, &sl_ );
+						}
+					}
 					const unsigned long long	m = __ballot( keep );
 					if( m ){
 						int	base = 0;
@@ -1944,9 +2075,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 							unsigned	*e = pool + RMK_POOL_WORDS * size_t( base + __popcll( m & lt_mask ) );
 							e[ 3 ] = hm[ 0 ];
 							e[ 4 ] = hm[ 1 ];
-							e[ 0 ] = unsigned( seq );
-							e[ 1 ] = unsigned( z0 + int( item >> 16 ) );
-							e[ 2 ] = ( item & 0xffffu ) | ( unsigned( sink.comp ) << 16 );
+							e[ 0 ] = unsigned( p_seq );
+							e[ 1 ] = unsigned( p_szero );
+							e[ 2 ] = unsigned( p_r ) | ( unsigned( sink.comp ) << 16 );
 						}
 					}
 				}
@@ -2253,11 +2384,11 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 
 // ---------------------------------------------------------------- launchers
 // One per translation unit (rm_scan_inst_*.hip): the instance's dynamic LDS limit and its launch.
-#define RMK_DEFINE_LAUNCHER( name_, LEAN_, G_, KINDS_, POOL_ ) \
+#define RMK_DEFINE_LAUNCHER( name_, LEAN_, G_, KINDS_, POOL_, ... ) \
 hipError_t name_( int grid, size_t lds, hipStream_t s, const rmk_search_args &a ) \
 { \
 	constexpr int	BLOCK_ = ( LEAN_ ) ? SEARCH_BLOCK : GENERAL_BLOCK; \
-	auto	kernel = &rma_search_kernel<BLOCK_, LEAN_, G_, KINDS_, POOL_>; \
+	auto	kernel = &rma_search_kernel<BLOCK_, LEAN_, G_, KINDS_, POOL_ __VA_OPT__(,) __VA_ARGS__>; \
 	hipError_t	e = hipFuncSetAttribute( reinterpret_cast<const void *>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ); \
 	if( e != hipSuccess ) \
 		return e; \

@@ -141,7 +141,7 @@ struct Options {
 	int	glist = 0;		// > 0: items of the drain kernel's list (tests: a list that overflows), 0: by the database's size
 	int	drain_waves = 0;	// > 0: workgroups (of one wave) of the drain kernel per CU instead of what LDS and registers allow
 	int	host_sort = 0, timing = 0;
-	int	short_force = -1;	// -1: by the mean entry length, 0 never, 1 always groups of small tiles
+	int	short_force = -1;	// -1: by the mean entry length, 0 never, 1 always groups of small tiles, 2 always tiles over the concatenation
 	int	tile = 0, qcap = 0;	// forced tile size / queue entries, 0: computed
 	int	spill = -1;		// forced spill area, -1: SPILL_ITEMS
 	int	budget = 0;
@@ -162,7 +162,7 @@ struct Options {
 		host_sort = env_int( "RNAMOTIF_HOSTSORT", 0 );
 		timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
 		if( const char *f = getenv( "RNAMOTIF_SHORT" ) )
-			short_force = f[ 0 ] == '1' ? 1 : 0;
+			short_force = f[ 0 ] == '1' ? 1 : f[ 0 ] == '2' ? 2 : 0;
 		tile = env_int( "RNAMOTIF_TILE", 0 );
 		if( tile < 0 || tile > 16384 )
 			tile = 0;
@@ -175,12 +175,22 @@ struct Options {
 // the tiling of a database for one launch shape
 struct Layout {
 	int	tile_t = 0, dminlen = 0, strands = 0, group = 1, qcap = 0;
+	// Tiles over the CONCATENATION of the entries (round 4; databases of short entries, pooled lean instance): a
+	// strand of the whole packed array -- the entries one after the other, each padded to 32 bases -- is tiled as
+	// if it were one long entry, so that the vectors of a tile are full whatever the entries' lengths; what a
+	// tile's tests let through is brought back to its entry when it enters the pool (super_convert in the kernel).
+	bool	concat = false;
+	int64_t	concat_bases = 0;
 	Block	blk;
 	int64_t	*d_tile_start = nullptr;
 	int32_t	*d_tile_seq = nullptr;
 	int64_t	n_tiles = 0;
 	std::vector<int64_t>	h_tile_start;	// (what the copies read: alive as long as the layout)
 	std::vector<int32_t>	h_tile_seq;
+	// one tile per workgroup pass: all a workgroup needs to know of tile t in one 32-byte line (RMK_META_*), so that it
+	// is one load -- made a tile ahead, straight into LDS -- instead of three dependent ones at the tile's start
+	int32_t	*d_tile_meta = nullptr;
+	std::vector<int32_t>	h_tile_meta;
 	hipEvent_t	ready = nullptr;	// the copies are complete: every scan waits for it on its stream
 	~Layout(){ if( ready != nullptr ) ( void )hipEventDestroy( ready ); }
 };
@@ -252,6 +262,8 @@ struct rma_db {
 	std::vector<int64_t>	h_base_off;
 	int32_t	n_seq = 0, max_slen = 0;
 	int64_t	total_bases = 0, sum_slen = 0;
+	int64_t	padded_bases = 0;	// bases the packed arrays hold, padding between the entries included
+	bool	ascending = true;	// the entries lie in the packed arrays in their order, none overlapping
 	hipEvent_t	ready = nullptr;	// the upload is complete (recorded on the upload stream)
 	std::mutex	mu;			// layouts, busy
 	std::vector<std::unique_ptr<Layout>>	layouts;
@@ -274,6 +286,7 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 {
 	switch( inst ){
 	case RMK_LEAN_POOL :	return rmk_launch_lean_pool( grid, lds, s, a );
+	case RMK_LEAN_CONCAT :	return rmk_launch_lean_concat( grid, lds, s, a );
 	case RMK_LEAN_GROUP :	return rmk_launch_lean_group( grid, lds, s, a );
 	case RMK_LEAN_TILE :	return rmk_launch_lean_tile( grid, lds, s, a );
 	case RMK_GEN_PLAIN :	return rmk_launch_gen_plain( grid, lds, s, a );
@@ -605,6 +618,10 @@ static int db_upload( int device, const std::vector<Piece> &pieces, const int64_
 	size_t	n_mask = 0;
 	for( const Piece &p : pieces )
 		n_mask += p.mask_words;
+	db->padded_bases = int64_t( n_mask ) * 32;
+	for( int i = 0; i < n; i++ )
+		if( base_off[ i ] < 0 || base_off[ i ] + slen[ i ] > db->padded_bases || ( i + 1 < n && base_off[ i ] + slen[ i ] > base_off[ i + 1 ] ) )
+			db->ascending = false;
 	const size_t	nn = size_t( std::max( n, 1 ) );
 	const size_t	o_codes = 0, o_amask = align256( std::max<size_t>( 2 * n_mask, 1 ) * 4 );
 	const size_t	o_off = o_amask + align256( std::max<size_t>( n_mask, 1 ) * 4 ), o_slen = o_off + align256( nn * 8 );
@@ -780,6 +797,11 @@ extern "C" void rma_db_destroy( rma_db_t *db )
 		( void )hipEventSynchronize( db->ready );	// (an upload still on its way into the block)
 		( void )hipEventDestroy( db->ready );
 	}
+	// (a tiling's two copies may still be on their way -- made by rma_db_attach() on a scanner's stream, or behind the
+	// words on the upload stream after db->ready was recorded: they read the layout's host vectors and write its block)
+	for( auto &l : db->layouts )
+		if( l->ready != nullptr )
+			( void )hipEventSynchronize( l->ready );
 	if( db->ctx != nullptr ){
 		db->ctx->give( db->blk );
 		for( auto &l : db->layouts )
@@ -817,6 +839,22 @@ extern "C" int rma_pack_pin( rma_pack_t *pack, char *err, size_t errlen )
 	return 0;
 }
 
+// the pooled lean instance (see the kernel): when the window of an item, four bits a base, fits the
+// column a lane gets of the tile's place in LDS
+static bool pooled_fits( const rma_scanner_t *sc, int tile_t )
+{
+	const rmd_program_t	&dp = sc->dprog;
+	if( !dp.lean_ok || ( sc->opt.dbg & 16 ) )
+		return false;
+	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 80;
+	const int	n_dw = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;
+	const size_t	room = size_t( ( tile_bytes + 15 ) & ~15 ) + size_t( 6 + ( dp.chain.on ? 1 : 0 ) ) * ( ( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
+	bool	pooled = n_dw <= 32 && size_t( n_dw ) * SEARCH_BLOCK * sizeof( uint32_t ) <= room;
+	if( sc->opt.pool >= 0 )		// 0: pass B tile by tile (tests, profiles/pool_matrix.py)
+		pooled = pooled && sc->opt.pool != 0;
+	return pooled;
+}
+
 // ---------------------------------------------------------------- tilings
 // The launch shape of database db under scanner sc, and its tiling.  Long entries: the scanner's
 // tile, one per workgroup pass.  A database of many short entries (GenBank divisions, transcript
@@ -837,6 +875,13 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	bool	grouped = n >= 64 && db->sum_slen / n < SHORT_ENTRY_MEAN && sc->opt.tile == 0 && !( sc->dprog.chain.on && sc->dprog.chain.hn_on );
 	if( sc->opt.short_force >= 0 )		// 0 never, 1 always (tests)
 		grouped = sc->opt.short_force == 1;
+	// Short entries and a descriptor the pooled instance takes: tiles over the concatenation of the entries (round 4)
+	// -- whole start positions only (no slices), entries in order in the packed arrays, positions within 30 bits.
+	const bool	short_db = n >= 64 && db->sum_slen / n < SHORT_ENTRY_MEAN && sc->opt.tile == 0;
+	bool	concat = ( sc->opt.short_force < 0 ? short_db : sc->opt.short_force == 2 ) && n >= 1 &&
+		db->h_pos_lo.empty() && db->ascending && db->padded_bases < ( int64_t( 1 ) << 30 ) && pooled_fits( sc, tile_t );
+	if( concat )
+		grouped = false;
 	if( grouped && sc->dprog.lean_ok && !( sc->opt.dbg & 16 ) ){
 		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64 - SHORT_GROUP * 32;
 		// (tiles of 1024 positions measured slower than of 768 where both fit: mp.ends 1.56 / 1.40 ms)
@@ -855,7 +900,7 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	const int	strands = sc->prog.chk_both_strs ? 2 : 1, dminlen = sc->prog.dminlen;
 	std::lock_guard<std::mutex>	lk( db->mu );
 	for( auto &l : db->layouts )
-		if( l->tile_t == tile_t && l->dminlen == dminlen && l->strands == strands && l->group == group && l->qcap == qcap )
+		if( l->tile_t == tile_t && l->dminlen == dminlen && l->strands == strands && l->group == group && l->qcap == qcap && l->concat == concat )
 			return l.get();
 	std::unique_ptr<Layout>	l( new Layout );
 	l->tile_t = tile_t;
@@ -863,8 +908,40 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	l->strands = strands;
 	l->group = group;
 	l->qcap = qcap;
+	l->concat = concat;
+	l->concat_bases = db->padded_bases;
 	std::vector<int64_t>	&tile_start = l->h_tile_start;
 	tile_start.assign( size_t( n ) + 1, 0 );
+	if( concat ){
+		// one "entry" of padded_bases bases per strand; a tile's line names the entries its start positions fall into
+		// (RMK_META_SEQ: the first, RMK_META_PAD: how many -- the search of an item's entry stays within them)
+		const int64_t	total = db->padded_bases, nsz = total - dminlen + 1;
+		const int64_t	nt = nsz > 0 ? ( nsz + tile_t - 1 ) / tile_t : 0;
+		l->n_tiles = nt * strands;
+		tile_start[ n ] = l->n_tiles;		// (nothing reads the per-entry sums of such a tiling)
+		l->h_tile_seq.assign( 1, 0 );
+		std::vector<int32_t>	&meta = l->h_tile_meta;
+		meta.assign( size_t( std::max<int64_t>( l->n_tiles, 1 ) ) * RMK_META_WORDS, 0 );
+		const std::vector<int64_t>	&bo = db->h_base_off;
+		auto entry_at = [ & ]( int64_t g ) -> int {	// the last entry that begins at or before base g of the arrays
+			const int	k = int( std::upper_bound( bo.begin(), bo.end(), g ) - bo.begin() ) - 1;
+			return k < 0 ? 0 : k;
+		};
+		for( int64_t t = 0; t < l->n_tiles; t++ ){
+			const int	comp = int( t / nt );
+			const int64_t	z0 = ( t % nt ) * tile_t, z1 = std::min<int64_t>( z0 + tile_t, nsz ) - 1;
+			const int64_t	g_lo = comp ? total - 1 - z1 : z0, g_hi = comp ? total - 1 - z0 : z1;
+			const int	k_lo = entry_at( g_lo ), k_hi = entry_at( g_hi );
+			int32_t	*m = &meta[ size_t( t ) * RMK_META_WORDS ];
+			m[ RMK_META_SEQ ] = k_lo;
+			m[ RMK_META_COMP ] = comp;
+			m[ RMK_META_Z0 ] = int32_t( z0 );
+			m[ RMK_META_SLEN ] = int32_t( total );
+			m[ RMK_META_OFF_LO ] = m[ RMK_META_OFF_HI ] = 0;
+			m[ RMK_META_POS_HI ] = 0x7fffffff;
+			m[ RMK_META_PAD ] = k_hi - k_lo + 1;
+		}
+	}else
 	for( int i = 0; i < n; i++ ){
 		int64_t	nsz = int64_t( db->h_slen[ i ] ) - dminlen + 1;	// start positions of a strand
 		if( !db->h_pos_lo.empty() )
@@ -874,12 +951,33 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	}
 	l->n_tiles = tile_start[ n ];
 	std::vector<int32_t>	&tile_seq = l->h_tile_seq;
-	tile_seq.resize( size_t( std::max<int64_t>( l->n_tiles, 1 ) ) );
-	for( int i = 0; i < n; i++ )
-		for( int64_t t = tile_start[ i ]; t < tile_start[ i + 1 ]; t++ )
-			tile_seq[ size_t( t ) ] = i;
-	const size_t	o_seq = align256( tile_start.size() * 8 );
-	hipError_t	e = db->ctx->take( o_seq + tile_seq.size() * 4, &l->blk );
+	if( !concat ){
+		tile_seq.resize( size_t( std::max<int64_t>( l->n_tiles, 1 ) ) );
+		for( int i = 0; i < n; i++ )
+			for( int64_t t = tile_start[ i ]; t < tile_start[ i + 1 ]; t++ )
+				tile_seq[ size_t( t ) ] = i;
+	}
+	std::vector<int32_t>	&tile_meta = l->h_tile_meta;
+	if( group == 1 && !concat ){
+		tile_meta.assign( size_t( std::max<int64_t>( l->n_tiles, 1 ) ) * RMK_META_WORDS, 0 );
+		for( int i = 0; i < n; i++ ){
+			const int64_t	per_strand = ( tile_start[ i + 1 ] - tile_start[ i ] ) / strands;
+			const int	lo = db->h_pos_lo.empty() ? 0 : db->h_pos_lo[ i ], hi = db->h_pos_hi.empty() ? 0x7fffffff : db->h_pos_hi[ i ];
+			for( int64_t t = tile_start[ i ]; t < tile_start[ i + 1 ]; t++ ){
+				int32_t	*m = &tile_meta[ size_t( t ) * RMK_META_WORDS ];
+				const int64_t	local = t - tile_start[ i ];
+				m[ RMK_META_SEQ ] = i;
+				m[ RMK_META_COMP ] = int32_t( local / per_strand );
+				m[ RMK_META_Z0 ] = lo + int32_t( local % per_strand ) * tile_t;
+				m[ RMK_META_SLEN ] = db->h_slen[ i ];
+				m[ RMK_META_OFF_LO ] = int32_t( uint64_t( db->h_base_off[ i ] ) & 0xffffffffu );
+				m[ RMK_META_OFF_HI ] = int32_t( uint64_t( db->h_base_off[ i ] ) >> 32 );
+				m[ RMK_META_POS_HI ] = hi;
+			}
+		}
+	}
+	const size_t	o_seq = align256( tile_start.size() * 8 ), o_meta = align256( o_seq + tile_seq.size() * 4 );
+	hipError_t	e = db->ctx->take( o_meta + tile_meta.size() * 4, &l->blk );
 	// On the stream given: the upload stream when the database is being made for a scanner (its first
 	// scan then finds the tiling there), else the scanner's.  The host copies stay with the layout and
 	// an event says when the copies are done, so nothing waits here.
@@ -890,6 +988,10 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	}
 	if( e == hipSuccess )
 		e = hipMemcpyAsync( l->d_tile_seq, tile_seq.data(), tile_seq.size() * 4, hipMemcpyHostToDevice, on );
+	if( e == hipSuccess && !tile_meta.empty() ){
+		l->d_tile_meta = reinterpret_cast<int32_t *>( static_cast<char *>( l->blk.p ) + o_meta );
+		e = hipMemcpyAsync( l->d_tile_meta, tile_meta.data(), tile_meta.size() * 4, hipMemcpyHostToDevice, on );
+	}
 	if( e == hipSuccess )
 		e = hipEventCreateWithFlags( &l->ready, hipEventDisableTiming );
 	if( e == hipSuccess )
@@ -922,6 +1024,8 @@ static DbView view_of( const rma_db *db, const Layout *l )
 	v.slen = db->d_slen;
 	v.tile_start = l->d_tile_start;
 	v.tile_seq = l->d_tile_seq;
+	v.tile_meta = l->d_tile_meta;
+	v.concat_bases = l->concat ? l->concat_bases : 0;
 	v.pos_lo = db->d_pos_lo;
 	v.pos_hi = db->d_pos_hi;
 	v.n_seq = db->n_seq;
@@ -941,9 +1045,9 @@ static int launch_search( rma_scanner_t *sc, char *err, size_t errlen )
 	a.prog_bytes = sc->prog_bytes;
 	a.qcap = f.lay->qcap;
 	a.db = view_of( f.db, f.lay );
-	const bool	drain = f.inst == RMK_LEAN_POOL && sc->glist_cap > 0;
+	const bool	drain = ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0;
 	a.hb = HitBuf{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap, sc->d_pool, sc->pool_cap,
-		sc->opt.pool_min, sc->opt.pool_refill, f.inst == RMK_LEAN_POOL ? sc->glist_cap : 0 };
+		sc->opt.pool_min, sc->opt.pool_refill, ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) ? sc->glist_cap : 0 };
 	a.tile_bytes = f.tile_bytes;
 	a.dbg = sc->opt.dbg | ( sc->whole_items ? 2097152 : 0 );
 	HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
@@ -986,11 +1090,11 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 			tot += double( ph[ i ] );
 		unsigned long long	lv[ 80 ];
 		( void )hipMemcpy( lv, sc->d_counters + 16, sizeof( lv ), hipMemcpyDeviceToHost );
-		if( f.lean && !( f.inst == RMK_LEAN_POOL && sc->glist_cap > 0 ) )
+		if( f.lean && !( ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0 ) )
 			fprintf( stderr, "[dbg] pool sessions: %.3g wave cycles popping (%.0f per round), %.3g stepping (%.0f per step)\n",
 				double( lv[ 4 ] ), lv[ 0 ] ? double( lv[ 4 ] ) / lv[ 0 ] : 0.0, double( lv[ 5 ] ), lv[ 2 ] ? double( lv[ 5 ] ) / lv[ 2 ] : 0.0 ),
 			fprintf( stderr, "[dbg] longest step %.3g cycles, most stepping in one wave (one session) %.3g cycles\n", double( lv[ 6 ] ), double( lv[ 7 ] ) );
-		if( f.inst == RMK_LEAN_POOL && sc->glist_cap > 0 ){
+		if( ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0 ){
 			// (the drain kernel's items)
 			unsigned long long	g[ 2 ];
 			( void )hipMemcpy( g, sc->d_counters + RMK_GCTL, sizeof( g ), hipMemcpyDeviceToHost );
@@ -1017,7 +1121,7 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 					fprintf( stderr, " %d:%llu,%.0f", kk, lv[ 61 + kk ], double( lv[ 45 + kk ] ) / lv[ 61 + kk ] );
 			fprintf( stderr, "\n" );
 		}
-		if( f.lean && !( f.inst == RMK_LEAN_POOL && sc->glist_cap > 0 ) )
+		if( f.lean && !( ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0 ) )
 			fprintf( stderr, "[dbg] pass B: %llu pop rounds of %.1f lanes, %llu steps of %.1f lanes; wave cycles popping %.1f%%, stepping %.1f%%\n",
 				lv[ 0 ], lv[ 0 ] ? double( lv[ 1 ] ) / lv[ 0 ] : 0.0, lv[ 2 ], lv[ 2 ] ? double( lv[ 3 ] ) / lv[ 2 ] : 0.0,
 				100.0 * lv[ 4 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ), 100.0 * lv[ 5 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ) );
@@ -1083,13 +1187,10 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	}
 	// the pooled lean instance (see the kernel): when the window of an item, four bits a base, fits the
 	// column a lane gets of the tile's place in LDS
-	bool	pooled = false;
-	if( f.lean && !f.grouped ){
-		const int	n_dw = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;
-		const size_t	room = size_t( ( f.tile_bytes + 15 ) & ~15 ) + size_t( 6 + ( dp.chain.on ? 1 : 0 ) ) * ( ( f.tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
-		pooled = n_dw <= 32 && size_t( n_dw ) * SEARCH_BLOCK * sizeof( uint32_t ) <= room;
-		if( sc->opt.pool >= 0 )		// 0: pass B tile by tile (tests, profiles/pool_matrix.py)
-			pooled = pooled && sc->opt.pool != 0;
+	const bool	pooled = f.lean && !f.grouped && pooled_fits( sc, lay->tile_t );
+	if( lay->concat && !pooled ){
+		snprintf( err, errlen, "a tiling over the concatenation of the entries is for the pooled instance only" );	// (layout_for asks pooled_fits too)
+		return 1;
 	}
 	if( pooled ){
 		// The list of the drain kernel: room for an item per 32 bases (trna.descr leaves one per 70 before the
@@ -1115,7 +1216,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	}
 	// the kernel instance: lean (pooled, one tile or a group of small ones per pass), or the general one
 	// compiled for the kinds of element the descriptor has
-	f.inst = pooled ? RMK_LEAN_POOL : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
+	f.inst = pooled ? ( lay->concat ? RMK_LEAN_CONCAT : RMK_LEAN_POOL ) : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
 		sc->kinds == 0 ? RMK_GEN_PLAIN : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ : RMK_GEN_PKTQ;
 	const int64_t	n_units = f.grouped ? ( lay->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : lay->n_tiles;
 	f.grid = int( std::min<int64_t>( n_units, f.lean ? sc->grid_blocks : sc->spill_blocks ) );

@@ -258,7 +258,8 @@ def test_tile_sizes_agree(built, workdir):
                                   "pk1.descr", "qu+tr.descr", "pk_j1+2.descr", "nanlin.descr"])
 def test_grouped_tiles_agree(built, workdir, gbrna, name):
     """Databases of short entries are searched in groups of small tiles that share one work
-    queue (rma_search_kernel<.., G>); the choice is a launch shape only.  The reference's test
+    queue (rma_search_kernel<.., G>), or -- descriptors the pooled lean instance takes -- in tiles over the
+    concatenation of the entries (Layout::concat); the choice is a launch shape only.  The reference's test
     database (4000 entries of 560 bases on average) and random entries of awkward lengths, one
     tile per pass against grouped, with an ample queue and with one that overflows."""
     import rnamotif_amd as R
@@ -270,7 +271,10 @@ def test_grouped_tiles_agree(built, workdir, gbrna, name):
     syn = [lut[rng.choice(5, size=n, p=[0.25, 0.25, 0.25, 0.24, 0.01])].tobytes() for n in lens * 4]
     for seqs, check_oracle in (([r[2] for r in R.read_fasta(gbrna)], False), (syn, True)):
         res = []
-        for short, qcap, spill in (("0", None, None), ("1", None, None), ("1", 64, None), ("1", 64, 0), ("0", 64, 32)):
+        # ("2": tiles over the concatenation of the entries -- round 4, the pooled lean instance; the queue of 64 with a spill
+        # area of 0 / 32 items sends items through the search in place, from the tile's bytes in their entry's coordinates)
+        for short, qcap, spill in (("0", None, None), ("1", None, None), ("1", 64, None), ("1", 64, 0), ("0", 64, 32),
+                                   ("2", None, None), ("2", 64, 32), ("2", 64, 0)):
             with _env(RNAMOTIF_SHORT=short, RNAMOTIF_QCAP=qcap, RNAMOTIF_SPILL=spill):
                 sc = R.Scanner(d)
                 res.append(sc.scan(sc.database(seqs)))
