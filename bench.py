@@ -294,6 +294,7 @@ def main():
     ap.add_argument("--resident", action="store_true", help="(kept for old command lines: the database staying in HBM is the default since round 4)")
     ap.add_argument("--h2d", action="store_true", help="every step uploads its batch (SURVEY.md 8d's step): then `value` is the PCIe-inclusive rate")
     ap.add_argument("--no-real-db", action="store_true", help="skip the real_db leg")
+    ap.add_argument("--serial", action="store_true", help="one scanner per descriptor: every step is ended before the next begins")
     ap.add_argument("--gather", choices=("native", "torch"), default="native", help="N > 1: rma_gather_hits (RCCL behind the C ABI) or torch.distributed")
     ap.add_argument("--backend", default=os.environ.get("RNAMOTIF_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo: tests with several ranks on one GPU)")
@@ -386,15 +387,23 @@ def main():
     def new_db(wait):
         return sc.database_from_pack(pack, wait=wait)
 
-    def scan_begin(db):
+    # Two scanners per descriptor, taking the steps in turns: the kernels of step i + 1 are launched before step i is
+    # ended, so the drain kernel, the energies, the ordering and the copy back of step i run under the search kernel of
+    # step i + 1 (each scanner has its own stream, hit buffer and lists; rma_scan_begin / rma_scan_end of the C ABI).
+    # A step is still one pass of the whole path over one batch, and every step begun inside the timed region is ended
+    # inside it; --serial ends every step before the next begins (the rate is in the `serial_steps` leg either way).
+    sets = [scs] if args.serial else [scs, [R.Scanner(d, device=dev_index) for d in descrs]]
+    pipe = {"i": 0, "pending": None}
+
+    def scan_begin(db, k=0):
         """Every descriptor's search kernel over db on its way, side by side on the scanners' streams."""
-        for s_ in scs:
+        for s_ in sets[k]:
             s_.scan_begin(db)
 
-    def scan_end():
+    def scan_end(k=0):
         """Energies, ordering, the records of all descriptors on rank 0; their number."""
         n = 0
-        for d_, s_ in zip(descrs, scs):
+        for d_, s_ in zip(descrs, sets[k]):
             if world == 1:
                 n += s_.scan_end(copy=False).shape[0]
             elif native is not None:
@@ -410,25 +419,43 @@ def main():
 
     state = {"cur": new_db(True)}
 
-    def step_h2d():
-        """The kernels of this batch are launched, then the next batch's upload is put on the upload stream
-        (its host side runs under the kernels), then this batch is finished; its block of HBM goes back to
-        the pool."""
-        scan_begin(state["cur"])
-        nxt = new_db(False)
-        n = scan_end()
-        state["cur"].close()
-        state["cur"] = nxt
+    def flush():
+        """The step still in flight is ended; its candidates."""
+        n = 0
+        if pipe["pending"] is not None:
+            k, old_db = pipe["pending"]
+            n = scan_end(k)
+            if old_db is not None:
+                old_db.close()
+            pipe["pending"] = None
         return n
 
+    def step_h2d():
+        """The kernels of this batch are launched, then the next batch's upload is put on the upload stream
+        (its host side runs under the kernels), then the batch before this one is finished; its block of HBM
+        goes back to the pool."""
+        k = pipe["i"] % len(sets)
+        pipe["i"] += 1
+        scan_begin(state["cur"], k)
+        nxt = new_db(False)
+        n = flush() if len(sets) > 1 else 0
+        pipe["pending"] = (k, state["cur"])
+        state["cur"] = nxt
+        return flush() if len(sets) == 1 else n
+
     def step_resident():
-        scan_begin(state["cur"])
-        return scan_end()
+        k = pipe["i"] % len(sets)
+        pipe["i"] += 1
+        scan_begin(state["cur"], k)
+        n = flush() if len(sets) > 1 else 0
+        pipe["pending"] = (k, None)
+        return flush() if len(sets) == 1 else n
 
     step = step_resident if args.resident else step_h2d
 
     for _ in range(args.warmup):
         step()
+    flush()
 
     def fence():
         if world > 1:
@@ -439,7 +466,8 @@ def main():
     t0 = time.perf_counter()
     total_hits = 0
     for _ in range(args.steps):
-        total_hits = step()
+        step()
+    total_hits = flush()                # (the last step is ended inside the timed region)
     state["cur"].wait()                 # (the upload the last step started is part of it)
     fence()
     dt = time.perf_counter() - t0
@@ -557,7 +585,8 @@ def main():
                                f"{args.records} x {args.record_len} base synthetic records per GPU")
                             + f" (iid uniform acgt, numpy default_rng({SEED})), both strands; " + where,
                 "step": "SURVEY.md 8d: H2D of the packed batch + search + efn + ordering + D2H of the hits" if not args.resident else
-                        "search kernel (+ drain kernel) + efn kernel + ordering + D2H of the hit records; the packed database is in HBM when the timed region starts",
+                        "search kernel (+ drain kernel) + efn kernel + ordering + D2H of the hit records; the packed database is in HBM when the timed region starts"
+                        + ("" if args.serial else "; two scanners take the steps in turns (step i's drain kernel, energies, ordering and copy back run under step i + 1's search kernel)"),
                 "bases_per_gpu": bases_per_gpu,
                 "total_bases": total_bases,
                 "candidates": total_hits,
@@ -593,10 +622,12 @@ def main():
     if rank == 0 and extras:
         def timed(fn, min_steps, min_s):
             fn()
+            flush()
             n, t0 = 0, time.perf_counter()
             while n < min_steps or time.perf_counter() - t0 < min_s:
                 fn()
                 n += 1
+            flush()
             state["cur"].wait()
             torch.cuda.synchronize()
             return n, time.perf_counter() - t0
@@ -613,6 +644,15 @@ def main():
         out["resident"] = {"value": round(db.bases * n_r / dr / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dr / n_r * 1e3, 3), "steps": n_r,
                            "what": "the same scan over a database that stays in HBM"}
         out["h2d_over_resident"] = round(out["h2d_inclusive"]["value"] / out["resident"]["value"], 3)
+        if len(sets) > 1:
+            # ... and one step ended before the next begins (one scanner, as until round 3)
+            both = sets[:]
+            del sets[1:]
+            n_s, d_s = timed(step_resident, 20, 0.5)
+            out["serial_steps"] = {"value": round(db.bases * n_s / d_s / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(d_s / n_s * 1e3, 3), "steps": n_s,
+                                   "what": "database resident, every step ended before the next begins: search kernel, drain kernel, energies, ordering and "
+                                           "copy back one after the other (`value` has two scanners take the steps in turns)"}
+            sets[:] = both
 
         # ---- the north star's own size on one GPU, and the whole command line over it
         if default_workload and args.north_star_records > n_rec and seqs_all is not None and len(seqs_all) >= args.north_star_records:

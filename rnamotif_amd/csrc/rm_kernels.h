@@ -98,6 +98,10 @@ enum rmk_instance {
 	RMK_GEN_PK,
 	RMK_GEN_TQ,
 	RMK_GEN_PKTQ,
+	RMK_GEN_PLAIN_CONCAT,	// the general instances over tiles that lie over the concatenation of the entries
+	RMK_GEN_PK_CONCAT,
+	RMK_GEN_TQ_CONCAT,
+	RMK_GEN_PKTQ_CONCAT,
 	RMK_N_INSTANCES
 };
 
@@ -121,6 +125,10 @@ hipError_t	rmk_launch_gen_plain( int grid, size_t lds, hipStream_t s, const rmk_
 hipError_t	rmk_launch_gen_pk( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_tq( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_pktq( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_plain_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_pk_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_tq_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_pktq_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 
 struct rmk_efn_args {
 	const rmd_program_t	*d_prog;

@@ -1,0 +1,4 @@
+// rm_scan_inst_gen_plain_concat.hip -- one instance of rma_search_kernel (rm_scan_kernel.h) and its launcher: the general instance
+// of this class of descriptor over tiles that lie over the concatenation of the entries (databases of short entries).
+#include "rm_scan_kernel.h"
+RMK_DEFINE_LAUNCHER( rmk_launch_gen_plain_concat, false, 1, 0, false, true )

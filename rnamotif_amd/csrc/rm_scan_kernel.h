@@ -552,13 +552,14 @@ struct GenTile {
 	const unsigned long long	*pb;
 	const uint8_t	*tile;
 	int	pb_words, p_lo, vec_words, slen, z0, split_s, dbg;
+	ConcatCtx	cc;		// (CONCAT instances: tiles over a concatenation of entries)
 };
 
 // (inlined: as a function of its own, called once per tile, it ran 15-25 % slower -- profiles/matrix_r2.sh)
 #ifndef PASS_B_ATTR
 #define PASS_B_ATTR	__attribute__(( always_inline ))
 #endif
-template< int BLOCK, int KINDS >
+template< int BLOCK, int KINDS, bool CONCAT = false >
 __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 {
 	const rmd_program_t	*const P = gt.P;
@@ -579,7 +580,24 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 			// every element type: 12 bytes of search state per level, in LDS (rmd_grec_t)
 			rmd_gen_t	st;
 			unsigned	cur_item = 0;
-			const RowEnds<KINDS>	ends{ pb, tile, pb_words, p_lo, ( dbg & 64 ) ? 0 : vec_words * 64 };	// (bit 64: end by end, no rows)
+			RowEnds<KINDS>	ends{ pb, tile, pb_words, p_lo, ( dbg & 64 ) ? 0 : vec_words * 64 };	// (bit 64: end by end, no rows)
+			// Tiles over a concatenation of entries (CONCAT): an item that is popped is brought to its entry's coordinates
+			// (super_convert) and walked there -- the tile's bytes and rows seen from the entry's first base, the entry's
+			// length and number; an item that belongs to no entry is dropped.  szero / r of the item at hand:
+			auto	item_begin = [ & ]( unsigned item, int *szero, int *r, int *islen ) -> bool {
+				*szero = z0 + int( item >> 16 );
+				*r = int( item & 0xffffu );
+				*islen = slen;
+				if constexpr( CONCAT ){
+					int	seq_e = 0, st_u = 0;
+					if( !super_convert( P, gt.cc.base_off, gt.cc.slens, gt.cc.total, sink.comp, gt.cc.k_lo, gt.cc.k_n, *szero, *r, &seq_e, szero, r, &st_u, islen ) )
+						return false;
+					sq.sq0 = p_lo - st_u;
+					ends.p_lo = p_lo - st_u;
+					sink.seq = seq_e;
+				}
+				return true;
+			};
 			const LdsSplit	split{ split_s, g_deep, &s_dqn, &cur_item };
 			// Two rounds over the tile.  Round 0: the work items, down to the split level; what
 			// survives there is queued as a continuation (LdsSplit), so the lanes stay together on the
@@ -607,15 +625,16 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 							else if( round == 0 ){
 								cur_item = i < qcap ? queue[ i ] :
 									__hip_atomic_load( spill + ( i - qcap ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-								const int	r = int( cur_item & 0xffffu );
-								k = rmd_gen_begin( P, gr, st, z0 + int( cur_item >> 16 ), slen,
-									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
+								int	i_sz, r, i_sl;
+								if( item_begin( cur_item, &i_sz, &r, &i_sl ) )
+									k = rmd_gen_begin( P, gr, st, i_sz, i_sl, r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1 );
 							}else{
 								const uint32_t	*e = g_deep + i * split.entry_words();
 								cur_item = e[ 0 ];
-								const int	r = int( cur_item & 0xffffu );
-								k = rmd_gen_resume( P, gr, st, sq, z0 + int( cur_item >> 16 ), slen,
-									r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1, split_s, e + 2, int( e[ 1 ] ), ends );
+								int	i_sz, r, i_sl;
+								if( item_begin( cur_item, &i_sz, &r, &i_sl ) )		// (always: it was walked to the split level from here)
+									k = rmd_gen_resume( P, gr, st, sq, i_sz, i_sl,
+										r == 0xffff ? 0 : r, r == 0xffff ? RMD_ALL_RANKS : 1, split_s, e + 2, int( e[ 1 ] ), ends );
 							}
 						}
 					}
@@ -931,7 +950,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 {
 	static_assert( G == 1 || ( LEAN && G % ( BLOCK / 64 ) == 0 && G <= 32 ), "tile groups: lean path, whole rounds of waves" );
 	static_assert( !POOL || ( LEAN && G == 1 ), "pooled pass B: lean path, one tile per pass" );
-	static_assert( !CONCAT || POOL, "tiles over a concatenation of entries: the pooled instance" );
+	static_assert( !CONCAT || POOL || !LEAN, "tiles over a concatenation of entries: the pooled lean instance and the general ones" );
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
 	// gP is the compact image (rmd_make_image): prog_bytes of it, a multiple of 16
@@ -2328,8 +2347,9 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			}
 		}else{
 			GenTile	gt{ P, lean_lo, g_before, g_deep, queue, spill, qcap, nq, &s_qhead, &s_dqn, &s_dqhead,
-				pb, tile, pb_words, p_lo, vec_words, slen, z0, split_s, dbg };
-			general_pass_b<BLOCK, KINDS>( gt, sink );
+				pb, tile, pb_words, p_lo, vec_words, slen, z0, split_s, dbg,
+				ConcatCtx{ db.base_off, db.slen, CONCAT ? db.concat_bases : 0ll, seq, ent_n } };
+			general_pass_b<BLOCK, KINDS, CONCAT>( gt, sink );
 		}
 		PHASE( 4 );
 		__syncthreads();

@@ -293,6 +293,10 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 	case RMK_GEN_PK :	return rmk_launch_gen_pk( grid, lds, s, a );
 	case RMK_GEN_TQ :	return rmk_launch_gen_tq( grid, lds, s, a );
 	case RMK_GEN_PKTQ :	return rmk_launch_gen_pktq( grid, lds, s, a );
+	case RMK_GEN_PLAIN_CONCAT :	return rmk_launch_gen_plain_concat( grid, lds, s, a );
+	case RMK_GEN_PK_CONCAT :	return rmk_launch_gen_pk_concat( grid, lds, s, a );
+	case RMK_GEN_TQ_CONCAT :	return rmk_launch_gen_tq_concat( grid, lds, s, a );
+	case RMK_GEN_PKTQ_CONCAT :	return rmk_launch_gen_pktq_concat( grid, lds, s, a );
 	}
 	return hipErrorInvalidValue;
 }
@@ -879,7 +883,8 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	// -- whole start positions only (no slices), entries in order in the packed arrays, positions within 30 bits.
 	const bool	short_db = n >= 64 && db->sum_slen / n < SHORT_ENTRY_MEAN && sc->opt.tile == 0;
 	bool	concat = ( sc->opt.short_force < 0 ? short_db : sc->opt.short_force == 2 ) && n >= 1 &&
-		db->h_pos_lo.empty() && db->ascending && db->padded_bases < ( int64_t( 1 ) << 30 ) && pooled_fits( sc, tile_t );
+		db->h_pos_lo.empty() && db->ascending && db->padded_bases < ( int64_t( 1 ) << 30 ) &&
+		( pooled_fits( sc, tile_t ) || !sc->dprog.lean_ok || ( sc->opt.dbg & 16 ) );		// (the pooled lean instance, or a general one)
 	if( concat )
 		grouped = false;
 	if( grouped && sc->dprog.lean_ok && !( sc->opt.dbg & 16 ) ){
@@ -1188,8 +1193,8 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	// the pooled lean instance (see the kernel): when the window of an item, four bits a base, fits the
 	// column a lane gets of the tile's place in LDS
 	const bool	pooled = f.lean && !f.grouped && pooled_fits( sc, lay->tile_t );
-	if( lay->concat && !pooled ){
-		snprintf( err, errlen, "a tiling over the concatenation of the entries is for the pooled instance only" );	// (layout_for asks pooled_fits too)
+	if( lay->concat && f.lean && !pooled ){
+		snprintf( err, errlen, "a tiling over the concatenation of the entries is for the pooled lean instance and the general ones" );	// (layout_for asks pooled_fits too)
 		return 1;
 	}
 	if( pooled ){
@@ -1217,6 +1222,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	// the kernel instance: lean (pooled, one tile or a group of small ones per pass), or the general one
 	// compiled for the kinds of element the descriptor has
 	f.inst = pooled ? ( lay->concat ? RMK_LEAN_CONCAT : RMK_LEAN_POOL ) : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
+		lay->concat ? ( sc->kinds == 0 ? RMK_GEN_PLAIN_CONCAT : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK_CONCAT : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ_CONCAT : RMK_GEN_PKTQ_CONCAT ) :
 		sc->kinds == 0 ? RMK_GEN_PLAIN : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ : RMK_GEN_PKTQ;
 	const int64_t	n_units = f.grouped ? ( lay->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : lay->n_tiles;
 	f.grid = int( std::min<int64_t>( n_units, f.lean ? sc->grid_blocks : sc->spill_blocks ) );
