@@ -55,7 +55,7 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # waves share the SIMD: 256 CUs x 4 SIMDs x 2.4 GHz / 2
 VALU_PEAK_NOMINAL = 256 * 4 * 2.4e9 / 2 / 1e9
 KERNEL_SOURCES = ("rm_scan_kernel.h", "rm_scan_core.h", "rm_dev_program.h", "rm_dev_program.cpp", "rm_efn_core.h", "rm_kernels.h")
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 PROFILE = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_trna")     # _pmc_summary.csv, _meta.json (profiles/collect.sh + summarize.py)
 SEED = 20240601
 

@@ -22,5 +22,10 @@ timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ
 	-d $O/pmc_sq2 --output-format csv -- python3 $B > $O/bench_sq2.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS \
 	-d $O/pmc_sq3 --output-format csv -- python3 $B > $O/bench_sq3.log 2>&1
+# (round 4: what the stall breakdown of profiles/stalls.py is made from)
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VALU SQ_INSTS_BRANCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES \
+	-d $O/pmc_sq4 --output-format csv -- python3 $B > $O/bench_sq4.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_IFETCH SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_FLAT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_CYCLES \
+	-d $O/pmc_sq5 --output-format csv -- python3 $B > $O/bench_sq5.log 2>&1
 grep -h '^{"metric"' $O/bench_plain.log | cut -c1-400
 ls $O
