@@ -184,8 +184,10 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		// every strand of a helix carries the group's rules (match_4plex reads them from q2)
 		bool	helix = e.type != RMA_T_SS && e.type != RMA_T_CTX;
 		if( helix ){
-			if( e.maxlen > RMD_MAX_HLEN )
+			if( e.maxlen > RMD_MAX_HLEN_WIDE )
 				return 1;
+			if( e.maxlen > RMD_MAX_HLEN )
+				out->wide = 1;
 			// find_motif.c:1023-1033
 			if( e.mispair > 0 ){
 				d->mplim = e.mispair;
@@ -200,7 +202,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			// one rule table per distinct (mispair, pairfrac) pair
 			rmd_rule_t	rule;
 			memset( &rule, 0, sizeof( rule ) );
-			for( int hl = 0; hl <= RMD_MAX_HLEN; hl++ ){
+			for( int hl = 0; hl <= RMD_MAX_HLEN_WIDE; hl++ ){
 				int	best = 0;
 				if( hl == 0 )
 					best = 255;
@@ -235,7 +237,7 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 			FAIL( "more than %d distinct helix mispair/pairfrac rules", RMD_MAX_RULES );
 		if( rc )
 			FAIL( "helix element %d allows %d base pairs; the device scanner takes at most %d",
-				i + 1, p->elems[ i ].maxlen, RMD_MAX_HLEN );
+				i + 1, p->elems[ i ].maxlen, RMD_MAX_HLEN_WIDE );
 	}
 	if( p->has_lctx )
 		cvt( p->lctx, &out->lctx );
@@ -273,7 +275,8 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 		}
 	}
 	// (window below 4096: the lean records pack positions into 12 bits, rm_scan_hip.hip)
-	out->lean_ok = p->n_searches <= RMD_LEAN_LEVELS && out->w_winsize < 4096 && p->n_elems <= 64;	// (64: an element per lane, the kernel's WaveTable)
+	out->lean_ok = p->n_searches <= RMD_LEAN_LEVELS && out->w_winsize < 4096 && p->n_elems <= 64 &&	// (64: an element per lane, the kernel's WaveTable)
+		!out->wide;		// (the lean records hold a helix length in six bits)
 	for( int s = 0; s < p->n_searches; s++ ){
 		const rma_elem_t	&e = p->elems[ p->searches[ s ] ];
 		if( !( e.type == RMA_T_SS || ( e.type == RMA_T_H5 && e.proper ) ) )
@@ -754,13 +757,13 @@ int rmd_build( const rma_program_t *p, rmd_program_t *out, char *err, size_t err
 	}
 	for( int k = 0; k < p->n_efn_sites; k++ ){
 		out->efn_sites[ k ] = p->efn_sites[ k ];
-		// the energy functions walk loops with fixed stacks (rm_efn_core.h RME_STK, rm_efn2_core.h
-		// RME2_MAXHELIX): a call over more helices than they can hold is refused here, not answered wrongly
+		// the energy functions walk loops with fixed stacks (rm_efn_core.h rme_ctx_t::stk, rm_efn2_core.h rme2_ctx_t::max_helix):
+		// a call over more helices than the usual instance holds takes the instance sized for fifty
 		int	lo = p->efn_sites[ k ].idx, hi = p->efn_sites[ k ].idx2, helices = 0;
 		for( int d = std::max( 0, std::min( lo, hi ) ); d <= std::max( lo, hi ) && d < p->n_elems; d++ )
 			helices += p->elems[ d ].type == RMA_T_H5;
 		if( helices > 15 )
-			FAIL( "efn()/efn2() call over %d helices; the device scanner takes at most 15", helices );
+			out->efn_big = 1;		// (the energy kernel's instance with stacks for fifty helices)
 	}
 	// Best literal (optimize_query, compile.c:3315-3392; mm_classccnt, mm_regexp.c:232):
 	// the fixed-length seq= with the most "effective characters" whose offset from the

@@ -15,7 +15,8 @@
 #define RMD_MAX_ELEMS	100	// elements (and search levels) per descriptor: the reference's own limit, compile.c:49
 #endif
 #define RMD_LEAN_LEVELS	16	// most search levels the lean path takes
-#define RMD_MAX_HLEN	63	// longest helix strand: candidate sets are 64-bit masks
+#define RMD_MAX_HLEN	63	// longest helix strand where sets of lengths are one 64-bit word: the lean path, and every general instance but one
+#define RMD_MAX_HLEN_WIDE	127	// ... two words (rmd_lset_t, rm_scan_core.h): the general instance compiled for it (rmd_program_t::wide)
 #define RMD_MAX_RE	20
 #define RMD_MAX_PS	20
 #define RMD_MAX_RULES	16	// helix groups with their own mispair / pairfrac rule tables
@@ -141,8 +142,8 @@ struct rmd_pk_t {
 
 // length dependent helix rules, shared by the strands of one helix
 struct rmd_rule_t {
-	uint8_t	pf_maxmpr[ RMD_MAX_HLEN + 1 ];	// pairfrac test: most mispairs allowed at length hl
-	uint8_t	tq_mplim[ RMD_MAX_HLEN + 1 ];	// match_triplex/match_4plex limit at length tlen
+	uint8_t	pf_maxmpr[ RMD_MAX_HLEN_WIDE + 1 ];	// pairfrac test: most mispairs allowed at length hl
+	uint8_t	tq_mplim[ RMD_MAX_HLEN_WIDE + 1 ];	// match_triplex/match_4plex limit at length tlen
 };
 
 struct rmd_site_t {
@@ -220,6 +221,8 @@ struct rmd_program_t {
 	int32_t	has_lctx, has_rctx;
 	int32_t	n_sites, n_efn;
 	int32_t	efn_usestdbp, efn_stdbp;
+	int32_t	wide;			// some helix may be longer than 63 base pairs: the general instance with two-word sets of lengths
+	int32_t	efn_big;		// some efn() / efn2() call spans more than 15 helices: the energy kernel's instance for that
 	int32_t	hit_stride;
 	int32_t	lmargin, rmargin;	// bases needed before szero / after the window
 	// best-literal pre-filter (the role of the reference's -O, compile.c:3315): regex lit_re

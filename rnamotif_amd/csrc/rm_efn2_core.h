@@ -16,12 +16,11 @@
 #include "rm_efn_core.h"
 
 #define RME2_INF	RMA_EFN2_INFINITY
-#define RME2_MAXHELIX	16	// branches of one loop (the reference allows 100; a descriptor of
-				// RMD_MAX_ELEMS elements cannot reach 16)
-#define RME2_STK	32
-
-template< class Cand >
+// branches of one loop: 16 in the usual instance, 52 in the one for calls over more than 15 helices (BIG; the reference
+// allows 100, a descriptor of RMD_MAX_ELEMS elements cannot have more than fifty helices)
+template< class Cand, int BIG = 0 >
 struct rme2_ctx_t {
+	static constexpr int	max_helix = BIG ? 52 : 16, stk = BIG ? 128 : 32;
 	const rma_efn2data_t	*E;
 	const Cand	*C;
 	int	l_base;
@@ -119,7 +118,7 @@ template< class X > RMD_FN int rme2_hploop( const X &x, int i, int j )	// ef2_hp
 // closing stem as branch 0 and again as branch n.
 template< class X > RMD_FN int rme2_branches( const X &x, int ( *hx )[ 2 ], int n, bool closed )
 {
-	int	coax[ RME2_MAXHELIX + 1 ][ RME2_MAXHELIX + 1 ];
+	int	coax[ X::max_helix + 1 ][ X::max_helix + 1 ];
 	const int	l_base = x.l_base;
 	const int	m = closed ? n : n - 1;		// last index of the diagonal in use
 	for( int a = 0; a <= m; a++ )
@@ -190,8 +189,8 @@ template< class X > RMD_FN int rme2_efn2( const X &x )	// RM_efn2 :1103
 {
 	const rma_efn2data_t	*e = x.E;
 	const int	l_base = x.l_base;
-	int	stk_i[ RME2_STK ], stk_j[ RME2_STK ], sp = 0;
-	int	hx[ RME2_MAXHELIX + 1 ][ 2 ];
+	int	stk_i[ X::stk ], stk_j[ X::stk ], sp = 0;
+	int	hx[ X::max_helix + 1 ][ 2 ];
 	int	energy = 0;
 	stk_i[ sp ] = 0;
 	stk_j[ sp ] = l_base;
@@ -233,7 +232,7 @@ template< class X > RMD_FN int rme2_efn2( const X &x )	// RM_efn2 :1103
 					again = true;
 				}else{
 					n_helix++;
-					if( n_helix >= RME2_MAXHELIX )
+					if( n_helix >= X::max_helix )
 						return RME2_INF;
 					hx[ 0 ][ 0 ] = i;
 					hx[ 0 ][ 1 ] = j;
@@ -246,7 +245,7 @@ template< class X > RMD_FN int rme2_efn2( const X &x )	// RM_efn2 :1103
 						energy += rme2_aupen( x, p, q );
 						hx[ h ][ 1 ] = p;
 						hx[ h ][ 0 ] = q;
-						if( sp >= RME2_STK )
+						if( sp >= X::stk )
 							return RME2_INF;
 						stk_i[ sp ] = p;
 						stk_j[ sp ] = q;
@@ -274,7 +273,7 @@ template< class X > RMD_FN int rme2_efn2( const X &x )	// RM_efn2 :1103
 			}
 			i++;
 		}
-		if( n_helix >= RME2_MAXHELIX )
+		if( n_helix >= X::max_helix )
 			return RME2_INF;
 		int	p = 1;
 		for( int h = 0; h < n_helix; h++ ){
@@ -286,7 +285,7 @@ template< class X > RMD_FN int rme2_efn2( const X &x )	// RM_efn2 :1103
 			energy += rme2_aupen( x, p, q );
 			hx[ h ][ 1 ] = p;
 			hx[ h ][ 0 ] = q;
-			if( sp >= RME2_STK )
+			if( sp >= X::stk )
 				return RME2_INF;
 			stk_i[ sp ] = p;
 			stk_j[ sp ] = q;
@@ -299,7 +298,7 @@ template< class X > RMD_FN int rme2_efn2( const X &x )	// RM_efn2 :1103
 }
 
 // Energy of efn2 site k for the hit record w (do_sc_efnx, score.c:1672-1679, before the 0.01).
-template< class Seq >
+template< class Seq, int BIG = 0 >
 RMD_FN int rme2_site_energy( const rmd_program_t *P, const rma_efn2data_t *E, const Seq *sq, const int32_t *w, int k,
 	int16_t *bpbuf = nullptr, uint8_t *bcbuf = nullptr, int cache = 0 )
 {
@@ -311,7 +310,7 @@ RMD_FN int rme2_site_energy( const rmd_program_t *P, const rma_efn2data_t *E, co
 		return RME_INF;
 	if( bpbuf != nullptr && c.len <= cache )
 		c.fill_cache( bpbuf, bcbuf );
-	rme2_ctx_t< rme_cand_t<Seq> >	x;
+	rme2_ctx_t< rme_cand_t<Seq>, BIG >	x;
 	x.E = E;
 	x.C = &c;
 	x.l_base = c.len - 1;

@@ -51,8 +51,12 @@ struct rme_tables_t {
 
 // The candidate as efn sees it: bc( i ) = base code, bp( i ) = partner or -1,
 // both indexed from the first base of the call (setupefn's i).
-template< class Cand >
+// BIG: a call over more than 15 helices (the descriptor language allows fifty): stacks and tables of the loops' walks sized
+// for it -- an instance of the energy kernel of its own, chosen per descriptor (rmd_program_t::efn_big); the usual
+// instance keeps the small ones (a few hundred bytes of scratch memory a lane instead of twelve thousand).
+template< class Cand, int BIG = 0 >
 struct rme_ctx_t {
+	static constexpr int	stk = BIG ? 128 : 48;
 	const rme_tables_t	*T;
 	const Cand	*C;
 	int	l_base;
@@ -229,23 +233,23 @@ template< class X > RMD_FN int rme_hploop( const X &x, int i, int j )	// ef_hplo
 	return rval;
 }
 
-#define RME_STK	48
 
 // RM_efn( 0, l_base, 1 ), efn.c:1162
 template< class X > RMD_FN int rme_efn( const X &x )
 {
+	constexpr int	RME_STK = X::stk;
 	int	stk_i[ RME_STK ], stk_j[ RME_STK ];
-	unsigned long long	stk_open = 0;
+	unsigned long long	stk_open[ ( RME_STK + 63 ) / 64 ] = { 0 };
 	int	sp = 0, e = 0;
 	stk_i[ 0 ] = 0;
 	stk_j[ 0 ] = x.l_base;
-	stk_open = 1;
+	stk_open[ 0 ] = 1;
 	sp = 1;
 	const int	fbp = x.tab( RME_EPARAM + 5 ), helixp = x.tab( RME_EPARAM + 8 );
 	while( sp > 0 ){
 		sp--;
 		int	i = stk_i[ sp ], j = stk_j[ sp ];
-		int	open = int( ( stk_open >> sp ) & 1 );
+		int	open = int( ( stk_open[ sp >> 6 ] >> ( sp & 63 ) ) & 1 );
 		int	fb = open ? 0 : fbp;
 		int	done = 0;
 		// (RM_efn returns EFN_INFINITY itself from a call that meets a "knot", efn.c:1218,1262: what the call had
@@ -301,11 +305,11 @@ template< class X > RMD_FN int rme_efn( const X &x )
 			// push the right part first so the left one is evaluated first
 			stk_i[ sp ] = cut + 1;
 			stk_j[ sp ] = j;
-			stk_open = ( stk_open & ~( 1ull << sp ) ) | ( ( unsigned long long )open << sp );
+			stk_open[ sp >> 6 ] = ( stk_open[ sp >> 6 ] & ~( 1ull << ( sp & 63 ) ) ) | ( ( unsigned long long )open << ( sp & 63 ) );
 			sp++;
 			stk_i[ sp ] = i;
 			stk_j[ sp ] = cut;
-			stk_open = ( stk_open & ~( 1ull << sp ) ) | ( ( unsigned long long )open << sp );
+			stk_open[ sp >> 6 ] = ( stk_open[ sp >> 6 ] & ~( 1ull << ( sp & 63 ) ) ) | ( ( unsigned long long )open << ( sp & 63 ) );
 			sp++;
 			continue;
 		}
@@ -384,7 +388,7 @@ template< class X > RMD_FN int rme_efn( const X &x )
 			}
 			stk_i[ sp ] = is;
 			stk_j[ sp ] = js;
-			stk_open &= ~( 1ull << sp );
+			stk_open[ sp >> 6 ] &= ~( 1ull << ( sp & 63 ) );
 			sp++;
 			break;
 		}
@@ -510,7 +514,7 @@ struct rme_cand_t {
 // the 0.01 scaling (score.c:1672-1679).
 // (bpbuf/bcbuf: room for the base codes and partners of a call of up to cache bases; longer calls
 // compute them on demand from the hit record)
-template< class Seq >
+template< class Seq, int BIG = 0 >
 RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const Seq *sq, const int32_t *w, int k,
 	int16_t *bpbuf = nullptr, uint8_t *bcbuf = nullptr, int cache = 0 )
 {
@@ -522,7 +526,7 @@ RMD_FN int rme_site_energy( const rmd_program_t *P, const rme_tables_t *T, const
 		return RME_INF;
 	if( bpbuf != nullptr && c.len <= cache )
 		c.fill_cache( bpbuf, bcbuf );
-	rme_ctx_t< rme_cand_t<Seq> >	x;
+	rme_ctx_t< rme_cand_t<Seq>, BIG >	x;
 	x.T = T;
 	x.C = &c;
 	x.l_base = c.len - 1;

@@ -60,6 +60,7 @@ enum { RMK_META_SEQ = 0, RMK_META_COMP, RMK_META_Z0, RMK_META_SLEN, RMK_META_OFF
 #ifndef RMD_KIND_PK
 #define RMD_KIND_PK	1	// improper (pseudoknot) helices
 #define RMD_KIND_TQ	2	// parallel helices, triplexes, 4-plexes
+#define RMD_KIND_WIDE	4	// helices of 64 to 127 base pairs
 #endif
 // (... three with 168 registers for descriptors with triplexes / 4-plexes: qu+tr 46.4 -> 39.2 ms, where
 // pk1 went 7.5 -> 8.6 ms in round 2, with workgroups of four waves.  With workgroups of one wave three and four
@@ -98,6 +99,7 @@ enum rmk_instance {
 	RMK_GEN_PK,
 	RMK_GEN_TQ,
 	RMK_GEN_PKTQ,
+	RMK_GEN_WIDE,		// every element kind, helices of up to 127 base pairs (two-word sets of lengths)
 	RMK_GEN_PLAIN_CONCAT,	// the general instances over tiles that lie over the concatenation of the entries
 	RMK_GEN_PK_CONCAT,
 	RMK_GEN_TQ_CONCAT,
@@ -125,6 +127,7 @@ hipError_t	rmk_launch_gen_plain( int grid, size_t lds, hipStream_t s, const rmk_
 hipError_t	rmk_launch_gen_pk( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_tq( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_pktq( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_gen_wide( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_plain_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_pk_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_gen_tq_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
@@ -140,4 +143,5 @@ struct rmk_efn_args {
 	const rma_efn2data_t	*e2;	// efn2's tables, or null
 };
 hipError_t	rmk_launch_efn( int grid, hipStream_t s, const rmk_efn_args &a );
+hipError_t	rmk_launch_efn_big( int grid, hipStream_t s, const rmk_efn_args &a );	// (calls over more than 15 helices: rmd_program_t::efn_big)
 hipError_t	rmk_preload_efn( void );

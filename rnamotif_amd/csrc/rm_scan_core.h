@@ -278,17 +278,76 @@ RMD_FN int rmd_prefix_ok( const rmd_program_t *P, const rmd_elem_t &e, const SQ 
 	return 1;
 }
 
+// ---------------------------------------------------------------- sets of helix lengths
+// The candidates of a helix at one pair of ends are a set of lengths (the reference's h3[ 101 ] / hlen[] / n_mpr[] arrays,
+// find_motif.c:406): one 64-bit word for helices of up to 63 base pairs -- every descriptor of the reference's tests --
+// and two words (rmd_lset_t, round 4: lengths to 127) in the one kernel instance compiled for longer ones (RMD_KIND_WIDE).
+struct rmd_lset_t { uint64_t lo, hi; };
+RMD_FN void rmd_ls_clear( uint64_t &s ) { s = 0; }
+RMD_FN void rmd_ls_clear( rmd_lset_t &s ) { s.lo = s.hi = 0; }
+RMD_FN bool rmd_ls_none( uint64_t s ) { return s == 0; }
+RMD_FN bool rmd_ls_none( const rmd_lset_t &s ) { return ( s.lo | s.hi ) == 0; }
+RMD_FN void rmd_ls_add( uint64_t &s, int b ) { s |= 1ull << b; }
+RMD_FN void rmd_ls_add( rmd_lset_t &s, int b ) { if( b < 64 ) s.lo |= 1ull << b; else s.hi |= 1ull << ( b - 64 ); }
+RMD_FN int rmd_ls_first( uint64_t s ) { return rmd_ctz64( s ); }		// (s is not empty)
+RMD_FN int rmd_ls_first( const rmd_lset_t &s ) { return s.lo ? rmd_ctz64( s.lo ) : 64 + rmd_ctz64( s.hi ); }
+RMD_FN void rmd_ls_drop_first( uint64_t &s ) { s &= s - 1; }
+RMD_FN void rmd_ls_drop_first( rmd_lset_t &s ) { if( s.lo ) s.lo &= s.lo - 1; else s.hi &= s.hi - 1; }
+RMD_FN void rmd_ls_keep_above( uint64_t &s, int hl ) { s = hl >= 63 ? 0 : s & ~( ( 2ull << hl ) - 1 ); }	// lengths > hl
+RMD_FN void rmd_ls_keep_above( rmd_lset_t &s, int hl )
+{
+	if( hl >= 127 )
+		s.lo = s.hi = 0;
+	else if( hl >= 63 ){
+		s.lo = 0;
+		s.hi = hl == 63 ? s.hi : s.hi & ~( ( 2ull << ( hl - 64 ) ) - 1 );
+	}else
+		s.lo &= ~( ( 2ull << hl ) - 1 );
+}
+RMD_FN void rmd_ls_keep_range( uint64_t &s, int lo, int hi )		// lengths lo .. hi
+{
+	if( lo > 0 )
+		s = lo >= 64 ? 0 : s & ~( ( 1ull << lo ) - 1 );
+	if( hi < 63 )
+		s = hi < 0 ? 0 : s & ( ( 2ull << hi ) - 1 );
+}
+RMD_FN void rmd_ls_keep_range( rmd_lset_t &s, int lo, int hi )
+{
+	if( lo > 0 ){
+		if( lo >= 128 ) s.lo = s.hi = 0;
+		else if( lo >= 64 ){ s.lo = 0; s.hi &= ~( ( 1ull << ( lo - 64 ) ) - 1 ); }
+		else s.lo &= ~( ( 1ull << lo ) - 1 );
+	}
+	if( hi < 127 ){
+		if( hi < 0 ) s.lo = s.hi = 0;
+		else if( hi < 63 ){ s.hi = 0; s.lo &= ( 2ull << hi ) - 1; }
+		else if( hi == 63 ) s.hi = 0;
+		else s.hi &= ( 2ull << ( hi - 64 ) ) - 1;
+	}
+}
+RMD_FN void rmd_ls_keep_only( uint64_t &s, int b ) { s &= 1ull << b; }
+RMD_FN void rmd_ls_keep_only( rmd_lset_t &s, int b ) { if( b < 64 ){ s.lo &= 1ull << b; s.hi = 0; }else{ s.lo = 0; s.hi &= 1ull << ( b - 64 ); } }
+RMD_FN int rmd_ls_count_below( uint64_t s, int hl ) { return rmd_popc64( hl >= 64 ? s : s & ( ( 1ull << hl ) - 1 ) ); }	// members < hl
+RMD_FN int rmd_ls_count_below( const rmd_lset_t &s, int hl )
+{
+	if( hl <= 64 )
+		return rmd_popc64( hl == 64 ? s.lo : s.lo & ( ( 1ull << hl ) - 1 ) );
+	return rmd_popc64( s.lo ) + rmd_popc64( hl >= 128 ? s.hi : s.hi & ( ( 1ull << ( hl - 64 ) ) - 1 ) );
+}
+
 // ---------------------------------------------------------------- helix matchers
 // match_wchlx(), find_motif.c:975.  Every candidate ends at s3, so the result
 // is the set of accepted lengths (bit hl of *cand) and the mispair positions.
 // mm5/mm3: s_n_mismatches of the two strands, in (current value) and out.
-template< class SQ >
+template< class SQ, class LS = uint64_t >
 RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
-	int d5, int d3, int s5, int s3, int s3lim, uint64_t *cand, uint64_t *mis, int *pmm5, int *pmm3 )
+	int d5, int d3, int s5, int s3, int s3lim, LS *cand, LS *mis, int *pmm5, int *pmm3 )
 {
 	const rmd_elem_t	&stp = P->elems[ d5 ], &stp3 = P->elems[ d3 ];
 	RMD_COUNT( 4 );
-	uint64_t	c = 0, m = 0;
+	LS	c, m;
+	rmd_ls_clear( c );
+	rmd_ls_clear( m );
 	int	hl, mpr, l_bpr, mm5 = *pmm5, mm3 = *pmm3;
 	const uint32_t	mat2 = rmd_pairsets( P )[ stp.pairset ].mat2;	// (RM_paired :1291 for every pair below: the table once)
 
@@ -297,7 +356,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 		if( stp.re >= 0 && !rmd_chk_seq( P, stp, sq, s5, 0, &mm5 ) )
 			ok = 0;
 		if( ok && ( stp3.re < 0 || rmd_chk_seq( P, stp3, sq, s3 + 1, 0, &mm3 ) ) )
-			c |= 1;
+			rmd_ls_add( c, 0 );
 	}
 	if( ( ( mat2 >> ( rmd_code( sq, s5 ) * 5 + rmd_code( sq, s3 ) ) ) & 1u ) ){
 		hl = 1;
@@ -307,13 +366,13 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 		hl = 1;
 		mpr = 1;
 		l_bpr = 0;
-		m |= 1;
+		rmd_ls_add( m, 0 );
 	}else{
 		*pmm5 = mm5;
 		*pmm3 = mm3;
 		*cand = c;
 		*mis = m;
-		return c != 0;
+		return !rmd_ls_none( c );
 	}
 	for( ; ; ){
 		if( hl >= stp.minlen ){
@@ -327,7 +386,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 			else if( stp3.re >= 0 && !rmd_chk_seq( P, stp3, sq, s3 - hl + 1, hl, &mm3 ) )
 				ok = 0;
 			if( ok )
-				c |= 1ull << hl;
+				rmd_ls_add( c, hl );
 		}
 		if( !( s3 - hl + 1 >= s3lim ) )
 			break;
@@ -340,7 +399,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 			if( mpr > stp.mplim )
 				break;
 			l_bpr = 0;
-			m |= 1ull << hl;
+			rmd_ls_add( m, hl );
 		}
 		hl++;
 	}
@@ -348,7 +407,7 @@ RMD_FN int rmd_match_wchlx_mm( const rmd_program_t *P, const SQ &sq,
 	*pmm3 = mm3;
 	*cand = c;
 	*mis = m;
-	return c != 0;
+	return !rmd_ls_none( c );
 }
 
 // match_phlx(), find_motif.c:1114.  mm5/mm3: s_n_mismatches of the two strands, in and out.
@@ -1163,6 +1222,9 @@ RMD_FN bool rmd_pin_ok( const rmd_program_t *P, const rmd_seq_t &sq, int z, int 
 // instance per class of descriptor keeps the code, and with it the registers, of the others out):
 #define RMD_KIND_PK	1	// improper (pseudoknot) helices
 #define RMD_KIND_TQ	2	// parallel helices, triplexes, 4-plexes
+#define RMD_KIND_WIDE	4	// helices of 64 to 127 base pairs: sets of lengths are two words (rmd_lset_t)
+template< bool WIDE > struct rmd_lset_sel { using type = uint64_t; };
+template<> struct rmd_lset_sel<true> { using type = rmd_lset_t; };
 struct rmd_no_ends_t {
 	static constexpr int	kinds = RMD_KIND_PK | RMD_KIND_TQ;
 	RMD_FN_MEMBER bool	ends( const rmd_elem_t &, int, int, int, uint64_t * ) const { return false; }
@@ -1260,28 +1322,30 @@ RMD_GEN_FN bool rmd_gen_wchlx( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 	const rmd_elem_t &stp, rmd_grec_t &r, const Accel &accel )		// find_wchlx :400
 {
 	const int	z = st.szero, d = P->searches[ k ];
-	uint64_t	cand = 0, mis = 0;
+	typename rmd_lset_sel<( Accel::kinds & RMD_KIND_WIDE ) != 0>::type	cand, mis;
+	rmd_ls_clear( cand );
+	rmd_ls_clear( mis );
 	int	cur = r.sd + 1, mm5 = 0, mm3 = 0;
 	if( r.ph != 0 ){
 		// back at the helix: its remaining lengths at the same end position
 		r.ph = 0;
 		rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
 			rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 );
-		cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+		rmd_ls_keep_above( cand, r.hl );
 	}
 	for( ; ; ){
-		if( cand == 0 ){
+		if( rmd_ls_none( cand ) ){
 			if( !rmd_gen_next_sd( P, gr, st, sq, k, stp, r, &cur, accel ) )
 				return false;
 			mm5 = mm3 = 0;
 			if( !rmd_match_wchlx_mm( P, sq, d, stp.mates[ 0 ], z + r.zero, z + cur,
 				rmd_s3lim( r.zero, cur, stp.minilen, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 ) ){
-				cand = 0;
+				rmd_ls_clear( cand );
 				continue;
 			}
 		}
-		const int	hl = rmd_ctz64( cand );		// find_wchlx :435-460
-		cand &= cand - 1;
+		const int	hl = rmd_ls_first( cand );		// find_wchlx :435-460
+		rmd_ls_drop_first( cand );
 		if( cur - r.zero - 2 * hl + 1 > stp.maxilen )
 			continue;
 		if( !rmd_pin_ok( P, sq, z, stp.inner_s, r.zero + hl, cur - hl, cur - hl ) )
@@ -1304,7 +1368,10 @@ RMD_GEN_FN bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 {
 	const int	z = st.szero, d = P->searches[ k ], d3 = stp.mates[ 0 ];
 	const rmd_pk_t	&pk = rmd_pks( P )[ stp.pk ];
-	uint64_t	cand = 0, mis = 0;
+	using LS = typename rmd_lset_sel<( Accel::kinds & RMD_KIND_WIDE ) != 0>::type;
+	LS	cand, mis;
+	rmd_ls_clear( cand );
+	rmd_ls_clear( mis );
 	int	cur = r.sd + 1;			// end position in use (ph != 0)
 	int	i_minl = 0, i_maxl, l_s5 = 0, l_s3 = 0;
 	int	iL_last = 0, iR_last = 0, iL_minl = 0, iL_maxl = 0, iR_minl = 0, iR_maxl = 0;	// second helix, :571-598
@@ -1351,11 +1418,8 @@ RMD_GEN_FN bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 		return true;
 	};
 	// lengths hlo .. hhi of a candidate set
-	auto clip = [ & ]( uint64_t c ) -> uint64_t {
-		if( hlo > 0 )
-			c &= ~( ( 1ull << hlo ) - 1 );
-		if( hhi < 63 )
-			c &= ( 2ull << hhi ) - 1;
+	auto clip = [ & ]( LS c ) -> LS {
+		rmd_ls_keep_range( c, hlo, hhi );
 		return c;
 	};
 	{
@@ -1369,7 +1433,8 @@ RMD_GEN_FN bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 			const int	s5 = r.a - 1, s3 = r.c + 1;
 			int	mm5 = 0, mm3 = 0;
 			rmd_match_wchlx_mm( P, sq, d, d3, z + s5, z + s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ) + z, &cand, &mis, &mm5, &mm3 );
-			cand = r.hl >= 63 ? 0 : clip( cand ) & ~( ( 2ull << r.hl ) - 1 );
+			cand = clip( cand );
+			rmd_ls_keep_above( cand, r.hl );
 		}
 	}
 	for( ; ; ){
@@ -1434,11 +1499,11 @@ RMD_GEN_FN bool rmd_gen_pknot( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 		const int	s5 = r.a - 1, s3 = r.c + 1;
 		bool	found = false;
 		int	hl = 0;
-		while( cand != 0 ){
-			hl = rmd_ctz64( cand );
-			cand &= cand - 1;
+		while( !rmd_ls_none( cand ) ){
+			hl = rmd_ls_first( cand );
+			rmd_ls_drop_first( cand );
 			if( ( s3 - s5 + 1 ) - 2 * hl < i_minl ){
-				cand = 0;	// break: longer helices only get worse
+				rmd_ls_clear( cand );	// break: longer helices only get worse
 				break;
 			}
 			if( pk.hlx2 ){		// :613-627
@@ -1561,7 +1626,9 @@ RMD_GEN_FN bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 	const int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ];
 	const rmd_elem_t	&stp1 = P->elems[ d1 ], &stp2 = P->elems[ d2 ];
 	const int	i_minl = stp.minilen + stp1.minilen + stp2.minilen + 2 * stp.minlen;
-	uint64_t	cand = 0, mis = 0;
+	typename rmd_lset_sel<( Accel::kinds & RMD_KIND_WIDE ) != 0>::type	cand, mis;
+	rmd_ls_clear( cand );
+	rmd_ls_clear( mis );
 	int	cur = r.sd + 1;
 	bool	have_cand = false;		// cand holds the outer helix' lengths beyond r.hl
 	for( ; ; ){
@@ -1580,16 +1647,16 @@ RMD_GEN_FN bool rmd_gen_4plex( const rmd_program_t *P, GR &gr, rmd_gen_t &st, co
 				int	mm5 = 0, mm3 = 0;
 				rmd_match_wchlx_mm( P, sq, d, d3, z + r.zero, z + cur, rmd_s3lim( r.zero, cur, i_minl, stp.maxlen ) + z,
 					&cand, &mis, &mm5, &mm3 );
-				cand = r.hl >= 63 ? 0 : cand & ~( ( 2ull << r.hl ) - 1 );
+				rmd_ls_keep_above( cand, r.hl );
 				have_cand = true;
 			}
-			if( cand == 0 ){
+			if( rmd_ls_none( cand ) ){
 				r.ph = 0;
 				have_cand = false;
 				continue;
 			}
-			const int	hl = rmd_ctz64( cand );
-			cand &= cand - 1;
+			const int	hl = rmd_ls_first( cand );
+			rmd_ls_drop_first( cand );
 			r.hl = uint8_t( hl );
 			r.a = int16_t( r.zero + hl + stp.minilen );		// s1
 			r.c = int16_t( cur - hl - stp2.minilen );		// s2
@@ -1694,7 +1761,7 @@ RMD_GEN_FN void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, con
 		}
 		case RMA_T_H5 : {
 			const int	d3 = stp.mates[ 0 ], hl = r.hl;
-			uint64_t	cand, mis;
+			typename rmd_lset_sel<( KINDS & RMD_KIND_WIDE ) != 0>::type	cand, mis;
 			int	s5 = zero, s3 = cur, i_minl = stp.minilen, mm5 = 0, mm3 = 0;
 			if constexpr( PK ){
 			if( !stp.proper ){
@@ -1708,7 +1775,7 @@ RMD_GEN_FN void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, con
 			}
 			}
 			rmd_match_wchlx_mm( P, sq, d, d3, s5, s3, rmd_s3lim( s5, s3, i_minl, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
-			const int	mpr = rmd_popc64( mis & ( ( 1ull << hl ) - 1 ) );
+			const int	mpr = rmd_ls_count_below( mis, hl );
 			L->moff[ d ] = s5;
 			L->mlen[ d ] = hl;
 			L->moff[ d3 ] = s3 - hl + 1;
@@ -1754,7 +1821,7 @@ RMD_GEN_FN void rmd_gen_emit( const rmd_program_t *P, GR &gr, rmd_gen_t &st, con
 		case RMA_T_Q1 : if constexpr( TQ ){
 			const int	d1 = stp.mates[ 0 ], d2 = stp.mates[ 1 ], d3 = stp.mates[ 2 ], hl = r.hl;
 			const int	i_minl = stp.minilen + P->elems[ d1 ].minilen + P->elems[ d2 ].minilen + 2 * stp.minlen;
-			uint64_t	cand, mis;
+			typename rmd_lset_sel<( KINDS & RMD_KIND_WIDE ) != 0>::type	cand, mis;
 			int	n_mpr = 0, mm5 = 0, mm3 = 0, mm1 = 0, mm2 = 0;
 			rmd_match_wchlx_mm( P, sq, d, d3, zero, cur, rmd_s3lim( zero, cur, i_minl, stp.maxlen ), &cand, &mis, &mm5, &mm3 );
 			const int	s1 = z + r.a, s2 = z + r.c + 1;

@@ -2372,7 +2372,9 @@ struct DevSeq {
 // longer than EFN_CACHE bases (a cloverleaf is under 96) -- 136 KB in all -- and the candidates
 // are taken in a grid-stride loop, so the staging is paid once per CU and four waves share it.
 #define EFN_CACHE	96
-template< int BLOCK >
+// BIG: for descriptors with an efn() / efn2() call over more than 15 helices (rmd_program_t::efn_big): the loops' stacks sized
+// for fifty (rm_efn_core.h)
+template< int BLOCK, int BIG = 0 >
 __global__ void __launch_bounds__( BLOCK )
 rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
 	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc, const rma_efn2data_t *e2 )
@@ -2395,9 +2397,9 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 		DevSeq	sq{ db, db.base_off[ w[ 0 ] ], db.slen[ w[ 0 ] ], w[ 1 ] };
 		for( int k = 0; k < gP->n_efn; k++ ){
 			if( rmd_efn_sites( gP )[ k ].kind == RMA_EFN_KIND_EFN2 )
-				w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy( gP, e2, &sq, w, k, bpbuf, bcbuf, EFN_CACHE ) : RME2_INF;
+				w[ efn_off + k ] = e2 != nullptr ? rme2_site_energy<DevSeq, BIG>( gP, e2, &sq, w, k, bpbuf, bcbuf, EFN_CACHE ) : RME2_INF;
 			else if( g16 != nullptr )
-				w[ efn_off + k ] = rme_site_energy( gP, &T, &sq, w, k, bpbuf, bcbuf, EFN_CACHE );
+				w[ efn_off + k ] = rme_site_energy<DevSeq, BIG>( gP, &T, &sq, w, k, bpbuf, bcbuf, EFN_CACHE );
 		}
 	}
 }

@@ -293,6 +293,7 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 	case RMK_GEN_PK :	return rmk_launch_gen_pk( grid, lds, s, a );
 	case RMK_GEN_TQ :	return rmk_launch_gen_tq( grid, lds, s, a );
 	case RMK_GEN_PKTQ :	return rmk_launch_gen_pktq( grid, lds, s, a );
+	case RMK_GEN_WIDE :	return rmk_launch_gen_wide( grid, lds, s, a );
 	case RMK_GEN_PLAIN_CONCAT :	return rmk_launch_gen_plain_concat( grid, lds, s, a );
 	case RMK_GEN_PK_CONCAT :	return rmk_launch_gen_pk_concat( grid, lds, s, a );
 	case RMK_GEN_TQ_CONCAT :	return rmk_launch_gen_tq_concat( grid, lds, s, a );
@@ -884,7 +885,7 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	const bool	short_db = n >= 64 && db->sum_slen / n < SHORT_ENTRY_MEAN && sc->opt.tile == 0;
 	bool	concat = ( sc->opt.short_force < 0 ? short_db : sc->opt.short_force == 2 ) && n >= 1 &&
 		db->h_pos_lo.empty() && db->ascending && db->padded_bases < ( int64_t( 1 ) << 30 ) &&
-		( pooled_fits( sc, tile_t ) || !sc->dprog.lean_ok || ( sc->opt.dbg & 16 ) );		// (the pooled lean instance, or a general one)
+		( pooled_fits( sc, tile_t ) || !sc->dprog.lean_ok || ( sc->opt.dbg & 16 ) ) && !sc->dprog.wide;		// (the pooled lean instance, or a general one)
 	if( concat )
 		grouped = false;
 	if( grouped && sc->dprog.lean_ok && !( sc->opt.dbg & 16 ) ){
@@ -1222,6 +1223,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	// the kernel instance: lean (pooled, one tile or a group of small ones per pass), or the general one
 	// compiled for the kinds of element the descriptor has
 	f.inst = pooled ? ( lay->concat ? RMK_LEAN_CONCAT : RMK_LEAN_POOL ) : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
+		dp.wide ? RMK_GEN_WIDE :
 		lay->concat ? ( sc->kinds == 0 ? RMK_GEN_PLAIN_CONCAT : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK_CONCAT : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ_CONCAT : RMK_GEN_PKTQ_CONCAT ) :
 		sc->kinds == 0 ? RMK_GEN_PLAIN : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ : RMK_GEN_PKTQ;
 	const int64_t	n_units = f.grouped ? ( lay->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : lay->n_tiles;
@@ -1306,7 +1308,7 @@ static int launch_efn( rma_scanner_t *sc, int64_t count, char *err, size_t errle
 		sc->have_efn ? sc->d_t16 : nullptr, sc->d_tlkey, sc->d_loginc, sc->d_efn2 };
 	sc->efn_ran = true;
 	HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
-	HIPCHK( rmk_launch_efn( int( blocks ), sc->stream, a ) );
+	HIPCHK( sc->dprog.efn_big ? rmk_launch_efn_big( int( blocks ), sc->stream, a ) : rmk_launch_efn( int( blocks ), sc->stream, a ) );
 	HIPCHK( hipEventRecord( sc->ev[ 3 ], sc->stream ) );
 	return 0;
 }

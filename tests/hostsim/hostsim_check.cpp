@@ -93,7 +93,8 @@ struct HostSplit {
 // rmd_gen_skip_ends()'s accelerator as the kernel defines it (RowEnds, rm_scan_hip.hip), bit by
 // bit instead of from bit vectors: the first minlen pairs of (s5, end) within the mispair limit
 struct HostEnds {
-	static constexpr int	kinds = RMD_KIND_PK | RMD_KIND_TQ;
+	// (WIDE: the host runs the two-word sets of helix lengths -- the instance for helices of 64 to 127 base pairs -- on every descriptor)
+	static constexpr int	kinds = RMD_KIND_PK | RMD_KIND_TQ | RMD_KIND_WIDE;
 	const rmd_program_t	*P;
 	rmd_seq_t	sq;
 	int	slen;

@@ -3,7 +3,10 @@ reference takes these descriptors; this build has no CPU search path to fall bac
 refused before any scan -- at descriptor compilation or at rma_scanner_create(), whose host part
 (rmd_build) runs before a device is asked for, so the refusals are testable here.  What is NOT
 refused any more: up to 100 elements, the reference's own limit (compile.c:49); seq= expressions of
-64 to 127 positions (round 3: a two-word automaton, tests/test_gpu_parity.py::test_long_seq_expressions)."""
+64 to 127 positions (round 3: a two-word automaton, tests/test_gpu_parity.py::test_long_seq_expressions); efn() / efn2()
+helices of 64 to 127 base pairs (round 4: a general instance with two-word sets of helix lengths, the reference's h3[ 101 ],
+tests/test_gpu_parity.py::test_helices_of_64_to_127_base_pairs); calls over more than 15 helices (round 4: an instance of the energy kernel with stacks for the fifty helices a descriptor
+can have, tests/test_gpu_parity.py::test_energy_calls_over_many_helices)."""
 import os
 
 import pytest
@@ -11,9 +14,9 @@ import pytest
 import rnamotif_amd as R
 
 CASES = [
-    ("helix of up to 80 base pairs",
-     "descr\n\th5(minlen=4,maxlen=80)\n\t\tss(minlen=3,maxlen=8)\n\th3\n",
-     "scanner", "helix element 1 allows 80 base pairs; the device scanner takes at most 63"),
+    ("helix of up to 130 base pairs",
+     "descr\n\th5(minlen=4,maxlen=130)\n\t\tss(minlen=3,maxlen=8)\n\th3\n",
+     "scanner", "helix element 1 allows 130 base pairs; the device scanner takes at most 127"),
     ("seq= that expands to more than 127 positions",
      'descr\n\tss(minlen=130,maxlen=150,seq="^' + "acgt" * 32 + '")\n',
      "scanner", "a seq= expression expands to more than 127 positions"),
@@ -26,10 +29,6 @@ CASES = [
     ("iupac = 0 with a letter that is not acgt in seq=",
      'parms\n\tiupac = 0;\ndescr\n\tss(minlen=4,maxlen=10,seq="nnac")\n',
      "compile", "cannot run on the device scanner: literal 'n' is not one of acgt."),
-    ("efn() over more than 15 helices",
-     "descr\n" + "".join("\th5(tag='h%d',minlen=2,maxlen=3)\n\t\tss(len=3)\n\th3(tag='h%d')\n\tss(len=1)\n" % (i, i) for i in range(17)) +
-     "score\n\t{ SCORE = efn( h5['h0'], h3['h16'] ); }\n",
-     "scanner", "efn()/efn2() call over 17 helices; the device scanner takes at most 15"),
     ("more than 100 elements (the reference's own limit)",
      "descr\n" + "".join("\tss(len=1)\n" for _ in range(101)),
      "compile", "descr array size(100) exceeded."),
@@ -52,10 +51,13 @@ def test_refusal_and_its_words(built, tmp_path, what, text, where, message):
 
 
 def test_a_hundred_elements_are_taken(built, tmp_path):
-    """48 and 100 elements pass the host part of rma_scanner_create(); without a GPU the only
-    objection left is the missing device."""
+    """48 and 100 elements, a helix of up to 100 base pairs and an efn() call over 17 helices pass the host part of
+    rma_scanner_create(); without a GPU the only objection left is the missing device."""
     for text in ("descr\n" + "".join("\th5(minlen=2,maxlen=3)\n\t\tss(len=3)\n\th3\n\tss(len=1)\n" for _ in range(12)),
-                 "descr\n" + "".join("\tss(len=1)\n" for _ in range(100))):
+                 "descr\n" + "".join("\tss(len=1)\n" for _ in range(100)),
+                 "descr\n\th5(minlen=4,maxlen=100)\n\t\tss(minlen=3,maxlen=8)\n\th3\n",
+                 "descr\n" + "".join("\th5(tag='h%d',minlen=2,maxlen=3)\n\t\tss(len=3)\n\th3(tag='h%d')\n\tss(len=1)\n" % (i, i) for i in range(17)) +
+                 "score\n\t{ SCORE = efn( h5['h0'], h3['h16'] ); }\n"):
         path = tmp_path / "y.descr"
         path.write_text(text)
         d = R.Descriptor(["-descr", str(path)])

@@ -546,6 +546,62 @@ def test_efn2_sites_equal_oracle(built, workdir, gbrna, name):
         assert np.all(np.abs(e2) < 100000)          # closed structures: always defined
 
 
+def test_helices_of_64_to_127_base_pairs(built, tmp_path):
+    """Helices longer than 63 base pairs (refused until round 3): the general instance whose sets of helix lengths are two
+    words (rm_scan_core.h rmd_lset_t, RMD_KIND_WIDE; the reference keeps a helix' candidates in h3[ 101 ], find_motif.c:406).
+    Planted hairpins of 63 to 127 base pairs in random sequence, with and without a mispair: records equal the oracle's."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(5)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    comp = bytes.maketrans(b"acgt", b"tgca")
+    rnd = lambda n: lut[rng.integers(0, 4, size=n)].tobytes()        # noqa: E731
+    seqs = []
+    for hl, loop in ((70, 5), (64, 4), (100, 6), (63, 3), (90, 8), (127, 4)):
+        stem = rnd(hl)
+        seqs.append(rnd(30) + stem + rnd(loop) + stem.translate(comp)[::-1] + rnd(25))
+    seqs.append(rnd(3000))
+    for text, least in (("descr\n\th5(minlen=20,maxlen=110,mispair=1)\n\t\tss(minlen=3,maxlen=8)\n\th3\n", 1000),
+                        ("parms\n\twc += gu;\ndescr\n\th5(minlen=60,maxlen=127)\n\t\tss(minlen=3,maxlen=8)\n\th3\n", 500),
+                        # (a pseudoknot whose first helix may be that long)
+                        ("descr\n\th5(tag='a',minlen=30,maxlen=80)\n\t\tss(minlen=1,maxlen=3)\n\th5(tag='b',minlen=3,maxlen=4)\n"
+                         "\t\tss(minlen=0,maxlen=3)\n\th3(tag='a')\n\t\tss(minlen=1,maxlen=30)\n\th3(tag='b')\n", 500)):
+        (tmp_path / "wide.descr").write_text(text)
+        d = R.Descriptor(["-descr", str(tmp_path / "wide.descr")])
+        sc = R.Scanner(d)
+        got = sc.scan(sc.database(seqs))
+        want = oracle_scan(d, seqs)
+        assert want.shape[0] >= least
+        assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_energy_calls_over_many_helices(built, tmp_path):
+    """efn() and efn2() over seventeen hairpins side by side (refused until round 3: "at most 15"): the energy kernel's
+    instance with stacks for fifty helices (rm_efn_core.h rme_ctx_t<.., BIG>, rmd_program_t::efn_big); records, energies
+    included, equal the oracle's -- RM_efn / RM_efn2 of the reference have no such bound (efn.c:1162, efn2.c:1103)."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    text = ("parms\n\twc += gu;\ndescr\n" +
+            "".join("\th5(tag='h%d',minlen=2,maxlen=3)\n\t\tss(len=3)\n\th3(tag='h%d')\n\tss(minlen=1,maxlen=2)\n" % (i, i) for i in range(17)) +
+            "score\n\t{ e2 = efn2( h5['h0'], h3['h16'] ); SCORE = efn( h5['h0'], h3['h16'] ); }\n")
+    (tmp_path / "many.descr").write_text(text)
+    d = R.Descriptor(["-descr", str(tmp_path / "many.descr")])
+    rng = np.random.default_rng(31)
+    lut = np.frombuffer(b"acgt", dtype=np.uint8)
+    flank = lambda n: lut[rng.integers(0, 4, size=n)].tobytes()                      # noqa: E731
+    units = [b"gcaaagca", b"ggcttagtca", b"gtaaaaca", b"cgagacgaa", b"ggaaauca".replace(b"u", b"t")]
+    seqs = []
+    for k in range(4):
+        body = b"".join(units[int(i)] for i in rng.integers(0, len(units), size=17))
+        seqs.append(flank(40 + 7 * k) + body + flank(30))
+    sc = R.Scanner(d)
+    got = sc.scan(sc.database(seqs))
+    want = oracle_scan(d, seqs)
+    assert want.shape[0] >= 4
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.all(np.abs(got[:, d.efn_off + 1]) < 16000)          # efn() of seventeen hairpins side by side: defined
+
+
 def test_cli_efn2_equals_oracle_cli(built, workdir):
     """The command line program with an efn2() score: same bytes as the oracle-backed program
     (whose efn2 column is checked against the reference's efn2_drv in tests/test_efn2_oracle.py)."""
