@@ -71,6 +71,12 @@ typedef struct rma_regex {
 	int32_t	dollar;		/* trailing $ (CDOL)				*/
 	int32_t	n_atoms;
 	int32_t	fixed_len;	/* sum of lo if every atom has lo == hi, else -1 */
+	/* 1: the atoms accept MORE than the expression does -- a back reference \1 stands as ".*", a literal or class
+	 * member that is not one of acgt (iupac = 0) as "any letter that is not acgt", \< and \> as nothing: what the
+	 * packed database can tell.  The scan's records are then candidates by a necessary condition; the host applies
+	 * the whole expression to the text when it replays them (rma_replay_*, Replayer::one_hit), as chk_seq() would
+	 * have (find_motif.c:1810; step / advance, regexp.c:389-664). */
+	int32_t	loose;
 	rma_re_atom_t	atoms[ RMA_MAX_RE_ATOMS ];
 } rma_regex_t;
 

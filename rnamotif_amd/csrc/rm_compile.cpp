@@ -1467,7 +1467,7 @@ bool Descriptor::chk_len_seq( int n, Strel *egroup[] )	// :1502
 		if( stp->seq == nullptr || !stp->re || stp->re->err )
 			continue;
 		int	i1_minl, i1_maxl, mmok;
-		re_seqlen( *stp->re, *stp->seq == '^', &i1_minl, &i1_maxl, &mmok );
+		re_seqlen( *stp->re, *stp->seq == '^', &i1_minl, &i1_maxl, &mmok, &stderr_text );
 		if( !mmok && stp->mismatch > 0 ){
 			err = true;
 			note_error( "%s:%d mismatches not allowed in this seq.", wdfname, stp->lineno );
@@ -1911,6 +1911,16 @@ void Descriptor::to_program( rma_program_t *out )
 				fail( "%s:%d seq=\"%s\" cannot run on the device scanner: %s.", wdfname, st.lineno, st.seq, why.c_str() );
 			if( st.mismatch > 0 && out->regexes[ out->n_regexes ].fixed_len < 0 )
 				fail( "%s:%d mismatches not allowed in this seq.", wdfname, st.lineno );
+			if( out->regexes[ out->n_regexes ].loose ){
+				// (the host applies the whole expression when it replays a candidate: Replayer::one_hit -- to the elements
+				// of the motif; and without mismatches where \( \) or \1 are in it: mm_advance() steps over their bytes)
+				if( &st == lctx || &st == rctx )
+					fail( "%s:%d seq=\"%s\" of a context element cannot run on the device scanner: back references and letters that are not acgt are taken in the motif's elements only.", wdfname, st.lineno, st.seq );
+				if( st.mismatch > 0 )
+					for( const ReOp &op : st.re->ops )
+						if( op.kind == RE_BRA || op.kind == RE_KET || op.kind == RE_BACK )
+							fail( "%s:%d seq=\"%s\" cannot run on the device scanner: mismatches in an expression with \\( \\) or a back reference.", wdfname, st.lineno, st.seq );
+			}
 			e->re = out->n_regexes++;
 		}
 	};

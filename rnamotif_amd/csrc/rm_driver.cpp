@@ -17,6 +17,9 @@ Replayer::Replayer( Descriptor &d, const rma_program_t &prog, FILE *out )
 	: d_( d ), prog_( prog ), out_( out ), printer_( d, out )
 {
 	d_.score->out = out;
+	for( int e = 0; e < prog.n_elems; e++ )
+		if( prog.elems[ e ].re >= 0 && prog.regexes[ prog.elems[ e ].re ].loose )
+			loose_ = true;
 }
 
 void Replayer::set_out( FILE *out, bool header )
@@ -80,6 +83,27 @@ void Replayer::one_hit( const int32_t *w, const char *sid, const char *sdef, int
 		d_.rctx->matchoff = w[ ctx_off + 2 ];
 		d_.rctx->matchlen = w[ ctx_off + 3 ];
 	}
+	// Elements whose seq= the scan could only test loosely (rma_regex_t::loose: back references, letters that are not
+	// acgt with iupac = 0): chk_seq() of the reference on the element's text (find_motif.c:1810-1824 -- the substring, NUL
+	// terminated, through step() or, with mismatches, mm_step()).  A record that fails is no candidate of the reference's:
+	// neither counted nor scored.
+	if( loose_ )
+		for( int e = 0; e < prog_.n_elems; e++ ){
+			const int	ri = prog_.elems[ e ].re;
+			if( ri < 0 || !prog_.regexes[ ri ].loose )
+				continue;
+			Strel	&s = d_.descr[ e ];
+			chk_.assign( sbuf + s.matchoff, size_t( s.matchlen ) );
+			bool	ok;
+			if( s.mismatch > 0 ){
+				int	n_mm = 0;
+				ok = re_mm_step( *s.re, chk_.c_str(), *s.seq == '^', s.mismatch, &n_mm );
+				s.n_mismatches = n_mm;
+			}else
+				ok = re_step( *s.re, chk_.c_str(), *s.seq == '^' );
+			if( !ok )
+				return;
+		}
 	d_.nval->pval = ( void * )sid;
 	d_.cval->ival = comp;
 	d_.pval->ival = comp ? slen - d_.descr[ 0 ].matchoff : d_.descr[ 0 ].matchoff + 1;

@@ -56,6 +56,8 @@ public:
 private:
 	void	one_hit( const int32_t *w, const char *sid, const char *sdef, int slen, const char *sbuf, SearchStats &st );
 	std::vector<char>	text_;		// strand buffer of the entry in hand, filled window by window
+	bool	loose_ = false;		// some element's seq= was tested loosely by the scan: the whole expression here (one_hit)
+	std::string	chk_;
 	Descriptor	&d_;
 	const rma_program_t	&prog_;
 	FILE	*out_;

@@ -381,8 +381,104 @@ bool re_mm_step( const ReProg &re, const char *s, bool anchored, int l_mm, int *
 	return false;
 }
 
-void re_seqlen( const ReProg &re, bool caret, int *minl, int *maxl, int *mmok )
+// mm_seqlen() over an expression with \( \) or \1 in it.  The reference walks its byte code one opcode at a time and
+// has no case for CKET's and CBACK's group number, nor for CBACK itself (mm_regexp.c:79-84, :196-198): the number is read
+// as the next opcode -- 0, 1 and 3 fall to the default case, which says "mm_seqlen: %2d?" on stderr and goes on; 2 is CBRA
+// and swallows the byte behind it; 4 is CCHR and counts a base ... -- so the implied lengths of such an expression, and what
+// the compiler says about it, are what that walk makes of the bytes.  The same walk here, over the same bytes (opcode values
+// regexp.c:74-88; counts and characters are signed chars there).
+static void seqlen_of_bytes( const ReProg &re, bool caret, int *minl, int *maxl, int *mmok, std::string *diag )
 {
+	enum { CBRA = 2, CCHR = 4, CDOT = 8, CCL = 12, CDOL = 20, CCEOF = 22, CKET = 24, CBRC = 28, CLET = 30, CBACK = 36, NCCL = 40, STAR = 1, RNGE = 3 };
+	std::vector<signed char>	b;
+	for( const ReOp &op : re.ops ){
+		const int	rep = op.rep == REP_STAR ? STAR : op.rep == REP_RANGE ? RNGE : 0;
+		switch( op.kind ){
+		case RE_CHR :	b.push_back( ( signed char )( CCHR | rep ) ); b.push_back( ( signed char )op.c ); break;
+		case RE_DOT :	b.push_back( ( signed char )( CDOT | rep ) ); break;
+		case RE_CCL :
+		case RE_NCCL :
+			b.push_back( ( signed char )( ( op.kind == RE_CCL ? CCL : NCCL ) | rep ) );
+			for( int k = 0; k < 16; k++ )
+				b.push_back( ( signed char )op.set[ k ] );
+			break;
+		case RE_DOL :	b.push_back( CDOL ); break;
+		case RE_BRA :	b.push_back( CBRA ); b.push_back( ( signed char )op.c ); break;
+		case RE_KET :	b.push_back( CKET ); b.push_back( ( signed char )op.c ); break;
+		case RE_BACK :	b.push_back( ( signed char )( CBACK | ( op.rep == REP_STAR ? STAR : 0 ) ) ); b.push_back( ( signed char )op.c ); break;
+		case RE_BRC :	b.push_back( CBRC ); break;
+		case RE_LET :	b.push_back( CLET ); break;
+		}
+		if( op.rep == REP_RANGE && op.kind != RE_BRA && op.kind != RE_KET && op.kind != RE_BACK ){
+			b.push_back( ( signed char )op.lo );
+			b.push_back( ( signed char )op.hi );
+		}
+	}
+	b.push_back( CCEOF );
+	b.resize( b.size() + 40, CCEOF );		// (a walk that has lost its place stops here at the latest)
+	*minl = 0;
+	*maxl = RMA_UNDEF;
+	*mmok = 1;
+	bool	dol = false, star = false;
+	int	trng = RMA_UNDEF;
+	for( size_t i = 0; i < b.size() && b[ i ] != CCEOF; i++ ){
+		int	rng = RMA_UNDEF;
+		const signed char	*ep = &b[ i ];
+		switch( *ep ){
+		case CBRA :	i++; break;
+		case CKET :	break;
+		case CBRC :
+		case CLET :	*mmok = 0; break;
+		case CCHR :	( *minl )++; i++; break;
+		case CCHR | STAR :	star = true; *mmok = 0; i++; break;
+		case CCHR | RNGE :
+			*minl += ep[ 1 ];
+			rng = ep[ 2 ] - ep[ 1 ];
+			if( ep[ 1 ] != ep[ 2 ] )
+				*mmok = 0;
+			i += 3;
+			break;
+		case CDOT :	( *minl )++; break;
+		case CDOT | STAR :	star = true; *mmok = 0; break;
+		case CDOT | RNGE :
+			*minl += ep[ 1 ];
+			rng = ep[ 2 ] - ep[ 1 ];
+			if( ep[ 1 ] != ep[ 2 ] )
+				*mmok = 0;
+			i += 2;
+			break;
+		case CCL : case NCCL :	( *minl )++; i += 16; break;
+		case CCL | STAR : case NCCL | STAR :	star = true; *mmok = 0; i += 16; break;
+		case CCL | RNGE : case NCCL | RNGE :
+			*minl += ep[ 16 + 1 ];
+			rng = ep[ 16 + 2 ] - ep[ 16 + 1 ];
+			if( ep[ 16 + 1 ] != ep[ 16 + 2 ] )
+				*mmok = 0;
+			i += 18;
+			break;
+		case CDOL :	dol = true; break;
+		default :
+			if( diag ){
+				char	line[ 40 ];
+				snprintf( line, sizeof( line ), "mm_seqlen: %2d?\n", int( *ep ) );
+				*diag += line;
+			}
+			break;
+		}
+		if( rng != RMA_UNDEF )
+			trng = trng == RMA_UNDEF ? rng : trng + rng;
+	}
+	if( caret && dol && !star )
+		*maxl = trng == RMA_UNDEF ? *minl : *minl + trng;
+}
+
+void re_seqlen( const ReProg &re, bool caret, int *minl, int *maxl, int *mmok, std::string *diag )
+{
+	for( const ReOp &op : re.ops )
+		if( op.kind == RE_BRA || op.kind == RE_KET || op.kind == RE_BACK ){
+			seqlen_of_bytes( re, caret, minl, maxl, mmok, diag );
+			return;
+		}
 	*minl = 0;
 	*maxl = RMA_UNDEF;
 	*mmok = 1;
@@ -465,16 +561,32 @@ bool re_to_atoms( const ReProg &re, bool caret, rma_regex_t *out, std::string &w
 			if( i + 1 != re.ops.size() ){ why = "'$' inside a pattern"; return false; }
 			out->dollar = 1;
 			continue;
-		case RE_BACK :	why = "back reference in seq="; return false;
+		case RE_BACK :
+			// the text of a group again: any run of letters, as far as the packed database can tell (the host
+			// applies the expression itself when it replays the candidates: rma_regex_t::loose)
+			out->loose = 1;
+			at.mask = 0x1f;
+			at.kind = 1;
+			at.lo = 0;
+			at.hi = 255;
+			if( out->n_atoms >= RMA_MAX_RE_ATOMS ){ why = "seq= pattern too long"; return false; }
+			out->atoms[ out->n_atoms++ ] = at;
+			out->fixed_len = -1;
+			continue;
 		case RE_BRC :
-		case RE_LET :	why = "\\< or \\> in seq="; return false;
+		case RE_LET :
+			// \< and \> hold at an end of a string of letters at most: no base is asked for
+			out->loose = 1;
+			continue;
 		case RE_CHR : {
 			int	bc = code( op.c );
 			if( bc < 0 ){
-				why = std::string( "literal '" ) + char( op.c ) + "' is not one of acgt";
-				return false;
-			}
-			at.mask = uint8_t( 1u << bc );
+				// iupac = 0: the letter itself.  A sequence letter that is not acgt is all the packed database
+				// knows of it (code 4); anything that is no letter never occurs in a sequence
+				out->loose = 1;
+				at.mask = isalpha( op.c ) ? 0x10 : 0;
+			}else
+				at.mask = uint8_t( 1u << bc );
 			at.kind = 0;
 			break;
 		}
@@ -492,12 +604,14 @@ bool re_to_atoms( const ReProg &re, bool caret, rma_regex_t *out, std::string &w
 				if( bc >= 0 )
 					m |= 1u << bc;
 				else if( isalpha( ch ) && islower( ch ) ){
-					why = std::string( "class member '" ) + char( ch ) + "' is not one of acgt";
-					return false;
+					// a member that is not one of acgt: some of the letters behind code 4
+					out->loose = 1;
+					m |= 0x10;
 				}
 			}
 			if( op.kind == RE_NCCL ){
-				at.mask = uint8_t( ( ~m ) & 0x1f );	// every other letter is outside the set
+				// (every letter outside the set; with a member behind code 4 left out, the others behind it still match)
+				at.mask = uint8_t( ( ( ~m ) | 0x10 ) & 0x1f );
 				at.kind = 3;
 			}else{
 				at.mask = uint8_t( m );

@@ -50,11 +50,13 @@ bool	re_step( const ReProg &re, const char *s, bool anchored, ReMatch *m = nullp
 // left exactly as the reference leaves it (count of the last attempt).
 bool	re_mm_step( const ReProg &re, const char *s, bool anchored, int l_mm, int *n_mm );
 
-// mm_seqlen( stp, .. ) without the best-literal (-O) analysis.
-void	re_seqlen( const ReProg &re, bool caret, int *minl, int *maxl, int *mmok );
+// mm_seqlen( stp, .. ) without the best-literal (-O) analysis.  diag: what the reference's walk says on stderr about
+// opcodes it does not know (the group numbers behind \) and \1: "mm_seqlen:  0?"), appended.
+void	re_seqlen( const ReProg &re, bool caret, int *minl, int *maxl, int *mmok, std::string *diag = nullptr );
 
-// Reduce to the device form; false (with a message) for constructs the device
-// matcher does not take: back references, \< \>, literals outside acgt.
+// Reduce to the device form; false (with a message) for what it cannot hold ('$' inside, too many atoms).  Back
+// references, \< \> and letters that are not acgt come out as what the packed database can tell of them, and
+// rma_regex_t::loose says that the expression itself still has to be applied to the text (the host does, at replay).
 bool	re_to_atoms( const ReProg &re, bool caret, rma_regex_t *out, std::string &why );
 
 }	// namespace rma

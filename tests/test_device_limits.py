@@ -4,7 +4,8 @@ refused before any scan -- at descriptor compilation or at rma_scanner_create(),
 (rmd_build) runs before a device is asked for, so the refusals are testable here.  What is NOT
 refused any more: up to 100 elements, the reference's own limit (compile.c:49); seq= expressions of
 64 to 127 positions (round 3: a two-word automaton, tests/test_gpu_parity.py::test_long_seq_expressions); efn() / efn2()
-helices of 64 to 127 base pairs (round 4: a general instance with two-word sets of helix lengths, the reference's h3[ 101 ],
+back references and -- with iupac = 0 -- letters that are not acgt in seq= (round 4: the scan tests what the packed database
+can tell, the host applies the expression at replay, tests/test_loose_seq.py); helices of 64 to 127 base pairs (round 4: a general instance with two-word sets of helix lengths, the reference's h3[ 101 ],
 tests/test_gpu_parity.py::test_helices_of_64_to_127_base_pairs); calls over more than 15 helices (round 4: an instance of the energy kernel with stacks for the fifty helices a descriptor
 can have, tests/test_gpu_parity.py::test_energy_calls_over_many_helices)."""
 import os
@@ -23,12 +24,9 @@ CASES = [
     ("seq= of more than 128 atoms",
      'descr\n\tss(minlen=130,maxlen=150,seq="^' + "acgt" * 33 + '")\n',
      "compile", "cannot run on the device scanner: seq= pattern to"),
-    ("back-reference in seq=",
-     'descr\n\tss(minlen=4,maxlen=10,seq="\\(ac\\)g\\1")\n',
-     "compile", "cannot run on the device scanner"),
-    ("iupac = 0 with a letter that is not acgt in seq=",
-     'parms\n\tiupac = 0;\ndescr\n\tss(minlen=4,maxlen=10,seq="nnac")\n',
-     "compile", "cannot run on the device scanner: literal 'n' is not one of acgt."),
+    ("back reference and mismatches in one seq=",
+     'descr\n\tss(minlen=6,maxlen=6,seq="^\\(ac\\)g\\1",mismatch=1)\n',
+     "compile", "mismatches"),
     ("more than 100 elements (the reference's own limit)",
      "descr\n" + "".join("\tss(len=1)\n" for _ in range(101)),
      "compile", "descr array size(100) exceeded."),
