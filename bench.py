@@ -232,7 +232,7 @@ REAL_DB = os.path.join(ROOT, "tests", "golden", "test", "gbrna.111.0.fastn.gz")
 REAL_DB_COPIES = 44
 # candidates (before the score program) of one copy of the reference's test database: the oracle's counts, which
 # tests/test_gpu_parity.py::test_hit_records_equal_oracle and tests/test_hostsim.py hold the GPU records to
-REAL_DB_CANDIDATES = {"trna.descr": 1351, "mp.ends.descr": 580, "pk1.descr": 9385}
+REAL_DB_CANDIDATES = {"trna.descr": 1351, "mp.ends.descr": 580, "pk1.descr": 193}
 
 
 def real_db_leg(dev_index, names=("trna.descr", "pk1.descr", "mp.ends.descr")):

@@ -139,7 +139,9 @@ struct Options {
 	int	pool_min = 1024, pool_refill = 48;
 	int	drain = 1;		// pooled instance: the items are walked by a kernel of their own (0: by the workgroup that found them)
 	int	glist = 0;		// > 0: items of the drain kernel's list (tests: a list that overflows), 0: by the database's size
-	int	drain_waves = 0;	// > 0: workgroups (of one wave) of the drain kernel per CU instead of what LDS and registers allow
+	int	drain_waves = 6;	// workgroups (of one wave) of the drain kernel per CU; 0: what LDS and registers allow (16).  Six: the kernel alone
+				// is as fast as with 16 (profiles/overlap_try.py: 0.29 ms), and the next scan's search kernel starts beside it
+	int	search_wgs = 0;		// > 0: workgroups of a lean search kernel per CU (fewer than fit: another scanner's drain kernel runs beside it)
 	int	host_sort = 0, timing = 0;
 	int	short_force = -1;	// -1: by the mean entry length, 0 never, 1 always groups of small tiles, 2 always tiles over the concatenation
 	int	tile = 0, qcap = 0;	// forced tile size / queue entries, 0: computed
@@ -158,7 +160,8 @@ struct Options {
 		pool_refill = env_int( "RNAMOTIF_POOL_REFILL", 48 );
 		drain = env_int( "RNAMOTIF_DRAIN", 1 );
 		glist = env_int( "RNAMOTIF_GLIST", 0 );
-		drain_waves = env_int( "RNAMOTIF_DRAIN_WAVES", 0 );
+		drain_waves = env_int( "RNAMOTIF_DRAIN_WAVES", 6 );
+		search_wgs = env_int( "RNAMOTIF_SEARCH_WGS", 0 );
 		host_sort = env_int( "RNAMOTIF_HOSTSORT", 0 );
 		timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
 		if( const char *f = getenv( "RNAMOTIF_SHORT" ) )
@@ -510,6 +513,7 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 	else if( n == "drain" ) o.drain = value;
 	else if( n == "glist" ) o.glist = std::max( 0, value );
 	else if( n == "drain_waves" ) o.drain_waves = std::max( 0, value );
+	else if( n == "search_wgs" ) o.search_wgs = std::max( 0, value );
 	else if( n == "host_sort" ) o.host_sort = value;
 	else if( n == "timing" ) o.timing = value;
 	else if( n == "short" ) o.short_force = value;
@@ -522,7 +526,7 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 		sc->last_relabelled = false;
 	}else{
 		snprintf( err, errlen, "rma_scanner_set_option: no option '%s' that can change after creation "
-			"(dbg, pool, pool_min, pool_refill, drain, glist, drain_waves, host_sort, timing, short; forget_last)", n.c_str() );
+			"(dbg, pool, pool_min, pool_refill, drain, glist, drain_waves, search_wgs, host_sort, timing, short; forget_last)", n.c_str() );
 		return 1;
 	}
 	return 0;
@@ -1228,6 +1232,8 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 		sc->kinds == 0 ? RMK_GEN_PLAIN : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ : RMK_GEN_PKTQ;
 	const int64_t	n_units = f.grouped ? ( lay->n_tiles + SHORT_GROUP - 1 ) / SHORT_GROUP : lay->n_tiles;
 	f.grid = int( std::min<int64_t>( n_units, f.lean ? sc->grid_blocks : sc->spill_blocks ) );
+	if( f.lean && sc->opt.search_wgs > 0 )		// (option search_wgs: workgroups of a lean search kernel per CU -- room for another scanner's drain kernel beside it)
+		f.grid = std::min( f.grid, sc->opt.search_wgs * ( sc->grid_blocks / 8 ) );
 	// the database's upload and the tiling's, on the device's upload stream, come first
 	HIPCHK( hipStreamWaitEvent( sc->stream, db->ready, 0 ) );
 	HIPCHK( hipStreamWaitEvent( sc->stream, lay->ready, 0 ) );
