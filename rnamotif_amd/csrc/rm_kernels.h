@@ -51,6 +51,21 @@ enum { RMK_META_SEQ = 0, RMK_META_COMP, RMK_META_Z0, RMK_META_SLEN, RMK_META_OFF
 #define GEN_REC_BYTES	12
 // queue of continuations of the general instance (LdsSplit)
 #define DEEP_QUEUE	128
+#ifndef FLUSH_WAVES_PER_SIMD
+#define FLUSH_WAVES_PER_SIMD	5	// the pooled lean instance that walks nothing (rma_search_kernel, WALK = false): what it is compiled and tiled for ...
+#endif
+#ifndef TICKET_TILES
+#define TICKET_TILES		4	// tiles a ticket is good for (rma_search_kernel, one tile per pass) ...
+#endif
+#ifndef TICKET_TAIL
+#define TICKET_TAIL		3	// ... but for the last so many per workgroup, which go one by one
+#endif
+#ifndef DRAIN_WAVES_PER_SIMD
+#define DRAIN_WAVES_PER_SIMD	4	// what the drain kernel is compiled for (its registers: 128 at four)
+#endif
+#ifndef FLUSH_WGS_PER_CU
+#define FLUSH_WGS_PER_CU	5	// ... and the workgroups a CU gets of it (rma_scan_begin)
+#endif
 #ifndef SEARCH_WAVES_PER_SIMD
 #define SEARCH_WAVES_PER_SIMD	4
 #endif
@@ -93,6 +108,7 @@ enum { RMK_META_SEQ = 0, RMK_META_COMP, RMK_META_Z0, RMK_META_SLEN, RMK_META_OFF
 enum rmk_instance {
 	RMK_LEAN_POOL = 0,	// lean, pass B over a pool of survivors (the headline instance)
 	RMK_LEAN_CONCAT,	// ... with the tiles over the concatenation of the entries (databases of short entries)
+	RMK_LEAN_FLUSH,		// lean, every survivor of pass A' straight to the drain kernel's list: the search kernel walks nothing
 	RMK_LEAN_GROUP,		// lean, groups of SHORT_GROUP small tiles (databases of short entries)
 	RMK_LEAN_TILE,		// lean, pass B tile by tile
 	RMK_GEN_PLAIN,		// general, no pseudoknot, no triplex / 4-plex
@@ -120,6 +136,7 @@ hipError_t	rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 // the launchers behind it, one translation unit each (rm_scan_inst_*.hip)
 hipError_t	rmk_launch_lean_pool( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_lean_flush( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_drain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );	// (qcap: not used; tile_bytes: window dwords per lane)
 hipError_t	rmk_launch_lean_group( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_tile( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
@@ -143,5 +160,6 @@ struct rmk_efn_args {
 	const rma_efn2data_t	*e2;	// efn2's tables, or null
 };
 hipError_t	rmk_launch_efn( int grid, hipStream_t s, const rmk_efn_args &a );
+hipError_t	rmk_launch_efn_light( int grid, hipStream_t s, const rmk_efn_args &a );	// (grid: workgroups of 64 lanes)
 hipError_t	rmk_launch_efn_big( int grid, hipStream_t s, const rmk_efn_args &a );	// (calls over more than 15 helices: rmd_program_t::efn_big)
 hipError_t	rmk_preload_efn( void );

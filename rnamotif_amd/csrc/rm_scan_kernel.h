@@ -777,7 +777,7 @@ __device__ inline void pool_sub_piece( unsigned rc, unsigned h0, unsigned h1, in
 // barrier anywhere), every wave taking its fair share of the list, then more as lanes come free.
 #define DRAIN_BLOCK	64
 template< int BLOCK >
-__global__ void __launch_bounds__( BLOCK, SEARCH_WAVES_PER_SIMD )
+__global__ void __launch_bounds__( BLOCK, DRAIN_WAVES_PER_SIMD )
 rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb, int n_nib, int dbg )
 {
 	static_assert( BLOCK == 64, "one wave per workgroup" );
@@ -944,13 +944,18 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 // CONCAT (pooled instance): the tiles lie over the concatenation of the entries (DbView::concat_bases, super_convert) -- an
 // instance of its own, so that the instance for databases of long entries is, to the register, what it was without it
 // (the headline kernel sits at its 128 registers: a dozen more live values in pass A' cost it a quarter of its speed).
-template< int BLOCK, bool LEAN, int G, int KINDS = 0, bool POOL = false, bool CONCAT = false >
-__global__ void __launch_bounds__( BLOCK, LEAN ? SEARCH_WAVES_PER_SIMD : GENERAL_WAVES( KINDS ) )
+// WALK = false (pooled instance): the search kernel walks nothing.  What passes pass A' goes straight to the drain kernel's list,
+// cut into its pieces, a wave reserving its items' room with one atomic; queue overflow and a full list are REPORTED
+// (ticket[ RMK_GCTL + 1 ], ticket[ RMK_GCTL - 1 ] > glist_cap) and the host repeats the scan with larger areas, as the general
+// instances do -- no pool, no walk, no in-place search in the kernel: fewer registers, fewer barriers a tile.
+template< int BLOCK, bool LEAN, int G, int KINDS = 0, bool POOL = false, bool CONCAT = false, bool WALK = true >
+__global__ void __launch_bounds__( BLOCK, LEAN ? ( WALK ? SEARCH_WAVES_PER_SIMD : FLUSH_WAVES_PER_SIMD ) : GENERAL_WAVES( KINDS ) )
 rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db, HitBuf hb, int tile_bytes, int dbg )
 {
 	static_assert( G == 1 || ( LEAN && G % ( BLOCK / 64 ) == 0 && G <= 32 ), "tile groups: lean path, whole rounds of waves" );
 	static_assert( !POOL || ( LEAN && G == 1 ), "pooled pass B: lean path, one tile per pass" );
 	static_assert( !CONCAT || POOL || !LEAN, "tiles over a concatenation of entries: the pooled lean instance and the general ones" );
+	static_assert( WALK || POOL, "a search kernel that walks nothing: the pooled lean instance" );
 	extern __shared__ __align__( 16 ) unsigned char	smem[];
 	rmd_program_t	*P = reinterpret_cast<rmd_program_t *>( smem );
 	// gP is the compact image (rmd_make_image): prog_bytes of it, a multiple of 16
@@ -1025,7 +1030,8 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	// the chain's working vectors -- where each base stands (5), two groups' vectors, a stem-loop's cores --
 	// take the place of the search records, which are not in use before pass B
 	unsigned long long	*const tv = reinterpret_cast<unsigned long long *>( lean_lo );
-	const bool	chain_vecs = chain_on && size_t( P->n_searches ) * BLOCK * LEAN_REC_BYTES >= size_t( 10 ) * pb_words * sizeof( unsigned long long );
+	// (the instance that walks nothing has no records: the host gave the vectors their own room)
+	const bool	chain_vecs = chain_on && ( !WALK || size_t( P->n_searches ) * BLOCK * LEAN_REC_BYTES >= size_t( 10 ) * pb_words * sizeof( unsigned long long ) );
 	__shared__ int	s_inplace;		// this tile's pre-filter searched queue overflow in place: the records, and with them tv, were written
 	LdsRecs<BLOCK>	lr{ lean_lo + threadIdx.x, lean_hi + threadIdx.x };
 	// (the general instance's records take the same place; behind them the resume states of the
@@ -1092,10 +1098,28 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 	__shared__ __align__( 16 ) int	s_meta[ 2 ][ RMK_META_WORDS ];
 	__shared__ long long	s_tile_nx;
 	long long	t_next = 0, t_next2 = 0;
+	// One tile per pass: a ticket is good for TICKET_TILES tiles in a row, and only the last TICKET_TAIL tiles per workgroup go
+	// one by one, to even out the end.  Every ticket is an atomic on ONE word that all workgroups of all XCDs share; 25 000 of
+	// them (trna.descr, 100 Mbase) took the device 0.35 ms to serve, one after the other -- what profiles/flush_stages.py showed
+	// as the kernel's "decode" stage (0.346 ms with nothing but decode in it, 0.14 with the tiles dealt out in advance; that,
+	// though, leaves a workgroup that starts late -- behind another scanner's kernels -- with all its tiles still to do).
+	const long long	n_big = ( G == 1 && !( dbg & 67108864 ) && n_units > ( long long )TICKET_TAIL * gridDim.x ) ?
+		( n_units - ( long long )TICKET_TAIL * gridDim.x ) / TICKET_TILES : 0ll;
+	long long	t_run = 0, t_run_end = 0;
+	auto	take_tile = [ & ]() -> long long {
+		if( t_run < t_run_end )
+			return t_run++;
+		const long long	c = ( long long )atomicAdd( hb.ticket, 1ull );
+		if( c >= n_big )
+			return n_big * TICKET_TILES + ( c - n_big );
+		t_run = c * TICKET_TILES + 1;
+		t_run_end = ( c + 1 ) * TICKET_TILES;
+		return c * TICKET_TILES;
+	};
 	if( tid == 0 ){
-		t_next = ( long long )atomicAdd( hb.ticket, 1ull );
+		t_next = take_tile();
 		if constexpr( G == 1 ){
-			t_next2 = ( long long )atomicAdd( hb.ticket, 1ull );
+			t_next2 = take_tile();
 			if( t_next < db.n_tiles )
 				for( int k = 0; k < RMK_META_WORDS; k++ )
 					s_meta[ 0 ][ k ] = db.tile_meta[ t_next * RMK_META_WORDS + k ];
@@ -1110,11 +1134,11 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			if constexpr( G == 1 ){
 				t_next = t_next2;
 				if( t < n_units )
-					t_next2 = ( long long )atomicAdd( hb.ticket, 1ull );
+					t_next2 = take_tile();
 				s_tile_nx = t_next;
 			}else{
 				if( t < n_units )
-					t_next = ( long long )atomicAdd( hb.ticket, 1ull );
+					t_next = take_tile();
 			}
 			s_tile = t;
 			s_seq = 0;
@@ -1135,7 +1159,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 		bool	last = false;
 		if( t >= n_units ){
 			// (pooled: one more round, over a tile without start positions, for what the pool still holds)
-			if constexpr( POOL )
+			if constexpr( POOL && WALK )
 				last = true;
 			else
 				break;
@@ -1400,7 +1424,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 					over_ = true; \
 				/* (general instance: the launch is repeated with a spill area that holds the tile's items) */ \
 			} \
-			if constexpr( LEAN ){ \
+			if constexpr( LEAN && WALK ){ \
 				if( __ballot( over_ ) ){ \
 					/* items beyond the queue and its spill area are searched here and now */ \
 					s_inplace = 1; \
@@ -1982,6 +2006,10 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 			if( tid == 0 && s_qn > qtotal )
 				atomicMax( hb.ticket + 2, ( unsigned long long )s_qn );
 		}
+		if constexpr( !WALK ){
+			if( tid == 0 && s_qn > qtotal )
+				atomicMax( hb.ticket + ( RMK_GCTL + 1 ), ( unsigned long long )s_qn );
+		}
 		const int	nq = ( dbg & 1 ) ? 0 : ( s_qn < qtotal ? s_qn : qtotal );
 		if( ( dbg & 2 ) && tid == 0 )
 			atomicAdd( hb.ticket + 1, ( unsigned long long )s_qn );
@@ -2082,6 +2110,39 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 							keep = super_convert( P, db.base_off, db.slen, db.concat_bases, sink.comp, seq, ent_n, p_szero, p_r, &p_seq, &p_szero, &p_r, &st_u_, &sl_ );
 						}
 					}
+					if constexpr( !WALK ){
+						// straight to the drain kernel's list, piece by piece (pool_sub_count): the wave's items side by side
+						const unsigned	rc = unsigned( p_r ) | ( unsigned( sink.comp ) << 16 );
+						const bool	cut = !( dbg & 2097152 );		// (diagnostic: items go whole)
+						const int	n_p = !keep ? 0 : !cut ? 1 : pool_sub_count( rc, hm[ 0 ], hm[ 1 ] );
+						int	incl = n_p;
+						for( int o = 1; o < 64; o <<= 1 ){
+							const int	v = __shfl_up( incl, o );
+							if( lane_id >= o )
+								incl += v;
+						}
+						const int	tot = __shfl( incl, 63 );
+						if( tot > 0 ){
+							unsigned long long	g0 = 0;
+							if( lane_id == 0 )
+								g0 = atomicAdd( hb.ticket + ( RMK_GCTL - 1 ), ( unsigned long long )tot );
+							g0 = __shfl( g0, 0 );
+							// (a full list: what has room is written -- every place below the list's end has one owner --, the
+							// host sees more reserved than there is and repeats the scan with a list that holds it)
+							const long long	at = ( long long )g0 + incl - n_p;
+							for( int p = 0; p < n_p; p++ )
+								if( at + p < hb.glist_cap ){
+									unsigned	*o = hb.pool + ( at + p ) * RMK_POOL_WORDS;
+									o[ 0 ] = unsigned( p_seq );
+									o[ 1 ] = unsigned( p_szero );
+									if( cut )
+										pool_sub_piece( rc, hm[ 0 ], hm[ 1 ], p, o + 2, o + 3, o + 4 );
+									else
+										o[ 2 ] = rc, o[ 3 ] = hm[ 0 ], o[ 4 ] = hm[ 1 ];
+								}
+						}
+						continue;
+					}
 					const unsigned long long	m = __ballot( keep );
 					if( m ){
 						int	base = 0;
@@ -2102,6 +2163,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 			}
 			PHASE( 3 );
+			if constexpr( WALK ){
 			__syncthreads();
 			// What the workgroup's pool still holds at the end goes to the device-wide list the drain kernel works on
 			// (rma_drain_kernel) when it is too little to keep the workgroup's lanes busy: GLIST_BELOW items.  (Many
@@ -2258,6 +2320,7 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 				}
 				break;
 			}
+			}	// WALK
 		}else if constexpr( LEAN ){
 
 			// ss / proper-helix descriptors: 8 bytes of search state per level, in LDS
@@ -2372,25 +2435,39 @@ struct DevSeq {
 // longer than EFN_CACHE bases (a cloverleaf is under 96) -- 136 KB in all -- and the candidates
 // are taken in a grid-stride loop, so the staging is paid once per CU and four waves share it.
 #define EFN_CACHE	96
+#define EFN_LIGHT_LDS	( 64 * ( ( EFN_CACHE + 2 ) * 2 + EFN_CACHE + 4 ) )	// dynamic LDS of rma_efn_light_kernel
 // BIG: for descriptors with an efn() / efn2() call over more than 15 helices (rmd_program_t::efn_big): the loops' stacks sized
 // for fifty (rm_efn_core.h)
-template< int BLOCK, int BIG = 0 >
-__global__ void __launch_bounds__( BLOCK )
-rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
+// STAGE = false, BLOCK = 64 (rma_scan_begin's pipelined callers: two scanners in turns): a workgroup of one wave that reads the
+// tables where they are -- 61 KB that the caches hold -- and keeps 19 KB of LDS for its lanes' calls, at no more than 128
+// registers: it finds room on a CU next to the workgroups of a search kernel (the instance that walks nothing leaves 33 KB and
+// a wave per SIMD), where the staged form -- 136 KB -- waits until the other scanner's search kernel is through.
+template< int BLOCK, int BIG, bool STAGE >
+__device__ __forceinline__ void efn_body( const rmd_program_t *gP, const DbView &db, int32_t *hits, long long n_hits,
 	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc, const rma_efn2data_t *e2 )
 {
 	// tables staged 16 bytes per lane and step (the device copy is padded to a multiple of 8 entries)
-	__shared__ __align__( 16 ) int16_t	t16[ RME_N16_PAD ];
-	if( g16 != nullptr )
-		for( int i = threadIdx.x; i < RME_N16_PAD / 8; i += BLOCK )
-			reinterpret_cast<uint4 *>( t16 )[ i ] = reinterpret_cast<const uint4 *>( g16 )[ i ];
-	__syncthreads();
+	__shared__ __align__( 16 ) int16_t	t16_s[ STAGE ? RME_N16_PAD : 8 ];
+	const int16_t	*t16 = g16;
+	if constexpr( STAGE ){
+		if( g16 != nullptr )
+			for( int i = threadIdx.x; i < RME_N16_PAD / 8; i += BLOCK )
+				reinterpret_cast<uint4 *>( t16_s )[ i ] = reinterpret_cast<const uint4 *>( g16 )[ i ];
+		__syncthreads();
+		t16 = t16_s;
+	}
 	// per lane: base codes and partners of the call, when it is short enough
-	__shared__ int16_t	s_bp[ BLOCK ][ EFN_CACHE + 1 ];
-	__shared__ uint8_t	s_bc[ BLOCK ][ EFN_CACHE + 4 ];
+	// (STAGE = false: in dynamic LDS -- the compiler, not knowing how much there is, keeps to the registers the launch bounds ask for)
+	__shared__ int16_t	s_bp[ STAGE ? BLOCK : 1 ][ EFN_CACHE + 1 ];
+	__shared__ uint8_t	s_bc[ STAGE ? BLOCK : 1 ][ EFN_CACHE + 4 ];
 	rme_tables_t	T{ t16, tlkey, loginc };
-	int16_t	*bpbuf = s_bp[ threadIdx.x ];
-	uint8_t	*bcbuf = s_bc[ threadIdx.x ];
+	int16_t	*bpbuf = s_bp[ STAGE ? threadIdx.x : 0 ];
+	uint8_t	*bcbuf = s_bc[ STAGE ? threadIdx.x : 0 ];
+	if constexpr( !STAGE ){
+		extern __shared__ __align__( 16 ) unsigned char	efn_dyn[];
+		bpbuf = reinterpret_cast<int16_t *>( efn_dyn ) + threadIdx.x * ( EFN_CACHE + 2 );
+		bcbuf = efn_dyn + BLOCK * ( EFN_CACHE + 2 ) * sizeof( int16_t ) + threadIdx.x * ( EFN_CACHE + 4 );
+	}
 	const int	efn_off = RMA_HIT_HDR + 4 * gP->n_elems + 4;
 	for( long long h = ( long long )blockIdx.x * BLOCK + threadIdx.x; h < n_hits; h += ( long long )gridDim.x * BLOCK ){
 		int32_t	*w = hits + h * gP->hit_stride;
@@ -2402,6 +2479,23 @@ rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_h
 				w[ efn_off + k ] = rme_site_energy<DevSeq, BIG>( gP, &T, &sq, w, k, bpbuf, bcbuf, EFN_CACHE );
 		}
 	}
+}
+
+template< int BLOCK, int BIG = 0 >
+__global__ void __launch_bounds__( BLOCK )
+rma_efn_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
+	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc, const rma_efn2data_t *e2 )
+{
+	efn_body<BLOCK, BIG, true>( gP, db, hits, n_hits, g16, tlkey, loginc, e2 );
+}
+
+// (120 registers: four workgroups of the search instance that walks nothing, at 96 each, leave a SIMD 128)
+template< int BIG = 0 >
+__global__ void __launch_bounds__( 64, 4 )
+rma_efn_light_kernel( const rmd_program_t *gP, DbView db, int32_t *hits, long long n_hits,
+	const int16_t *g16, const int32_t *tlkey, const int32_t *loginc, const rma_efn2data_t *e2 )
+{
+	efn_body<64, BIG, false>( gP, db, hits, n_hits, g16, tlkey, loginc, e2 );
 }
 
 // ---------------------------------------------------------------- launchers

@@ -141,6 +141,8 @@ struct Options {
 	int	glist = 0;		// > 0: items of the drain kernel's list (tests: a list that overflows), 0: by the database's size
 	int	drain_waves = 6;	// workgroups (of one wave) of the drain kernel per CU; 0: what LDS and registers allow (16).  Six: the kernel alone
 				// is as fast as with 16 (profiles/overlap_try.py: 0.29 ms), and the next scan's search kernel starts beside it
+	int	flush = -1;		// pooled instance that walks nothing (RMK_LEAN_FLUSH): -1 where the descriptor has a look-ahead chain, 0 never, 1 wherever the pooled instance runs
+	int	efn_light = -1;		// the energy kernel in workgroups of one wave that stage no tables (rma_efn_light_kernel): -1 by the scan's instance, 0 never, 1 always
 	int	search_wgs = 0;		// > 0: workgroups of a lean search kernel per CU (fewer than fit: another scanner's drain kernel runs beside it)
 	int	host_sort = 0, timing = 0;
 	int	short_force = -1;	// -1: by the mean entry length, 0 never, 1 always groups of small tiles, 2 always tiles over the concatenation
@@ -162,6 +164,8 @@ struct Options {
 		glist = env_int( "RNAMOTIF_GLIST", 0 );
 		drain_waves = env_int( "RNAMOTIF_DRAIN_WAVES", 6 );
 		search_wgs = env_int( "RNAMOTIF_SEARCH_WGS", 0 );
+		flush = env_int( "RNAMOTIF_FLUSH", -1 );
+		efn_light = env_int( "RNAMOTIF_EFN_LIGHT", -1 );
 		host_sort = env_int( "RNAMOTIF_HOSTSORT", 0 );
 		timing = getenv( "RNAMOTIF_TIMING" ) != nullptr;
 		if( const char *f = getenv( "RNAMOTIF_SHORT" ) )
@@ -178,6 +182,7 @@ struct Options {
 // the tiling of a database for one launch shape
 struct Layout {
 	int	tile_t = 0, dminlen = 0, strands = 0, group = 1, qcap = 0;
+	bool	flush = false;		// tiles of the size of the pooled instance that walks nothing (RMK_LEAN_FLUSH)
 	// Tiles over the CONCATENATION of the entries (round 4; databases of short entries, pooled lean instance): a
 	// strand of the whole packed array -- the entries one after the other, each padded to 32 bases -- is tiled as
 	// if it were one long entry, so that the vectors of a tile are full whatever the entries' lengths; what a
@@ -225,6 +230,9 @@ struct rma_scanner {
 	int	spill_cap = 0;
 	bool	whole_items = false;		// ... which takes the items whole, not in pieces (see search_finish)
 	int	glist_cap = 0;			// pooled instance: items of the list the drain kernel walks (the head of d_pool)
+	int	glist_need = 0;			// ... and what a scan of the instance that walks nothing asked for (search_finish)
+	bool	flush = false;			// long entries are searched by RMK_LEAN_FLUSH, on tiles of its own size
+	int	tile_t_flush = 0, qcap_flush = 0;
 	unsigned	*d_pool = nullptr;		// [grid_blocks][pool_cap][3] pooled instance: items waiting for pass B
 	int	pool_cap = 0;
 	int32_t	*h_raw = nullptr;		// pinned
@@ -290,6 +298,7 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 	switch( inst ){
 	case RMK_LEAN_POOL :	return rmk_launch_lean_pool( grid, lds, s, a );
 	case RMK_LEAN_CONCAT :	return rmk_launch_lean_concat( grid, lds, s, a );
+	case RMK_LEAN_FLUSH :	return rmk_launch_lean_flush( grid, lds, s, a );
 	case RMK_LEAN_GROUP :	return rmk_launch_lean_group( grid, lds, s, a );
 	case RMK_LEAN_TILE :	return rmk_launch_lean_tile( grid, lds, s, a );
 	case RMK_GEN_PLAIN :	return rmk_launch_gen_plain( grid, lds, s, a );
@@ -306,7 +315,7 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 }
 
 // LDS of one search workgroup: program image | queue | tile | 6 bit vectors | lean records
-static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1 )
+static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int tile_t, bool lean, int qcap, int group = 1, bool flush = false )
 {
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 80;
 	// (bit vectors of a tile: the literal's, five per pair-row set, four of a leading 4-plex' strand filter, five more when a triplex follows it)
@@ -318,7 +327,11 @@ static size_t search_lds_bytes( int prog_bytes, const rmd_program_t &dp, int til
 		( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
 	size_t	lds = size_t( prog_bytes ) + size_t( qcap ) * sizeof( unsigned ) +
 		size_t( group ) * ( ( ( size_t( tile_bytes ) + 15 ) & ~size_t( 15 ) ) + pb_bytes );
-	lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;
+	// (the instance that walks nothing has no records: only the look-ahead chain's ten working vectors, which elsewhere borrow their place)
+	if( flush )
+		lds += dp.chain.on ? size_t( 10 ) * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long ) : 0;
+	else
+		lds += lean ? size_t( dp.n_searches ) * SEARCH_BLOCK * LEAN_REC_BYTES : size_t( dp.n_rec_dwords ) * GENERAL_BLOCK * 4;
 	if( lean && group > 1 && dp.lit_re >= 0 )	// (groups: the literal's five vectors once per wave, behind the records)
 		lds += 8 + size_t( SEARCH_BLOCK / 64 ) * 6 * ( size_t( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );	// (the sixth: the literal's start positions)
 	if( !lean && dp.split_s >= 0 )		// resume states of the levels up to the split level, queue of continuations
@@ -458,6 +471,32 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		const int	q_want = int( std::min( 8192.0, std::ceil( density * sc->tile_t * 1.2 / 256 ) * 256 ) );
 		while( sc->qcap + 256 <= q_want && search_lds_bytes( sc->prog_bytes, dp, sc->tile_t, true, sc->qcap + 256 ) <= budget )
 			sc->qcap += 256;
+		// The pooled instance that walks nothing (RMK_LEAN_FLUSH: every survivor of pass A' goes to the drain kernel's list):
+		// FLUSH_WAVES_PER_SIMD workgroups a CU, tiles as large as its smaller share of LDS holds without the search records.
+		// For descriptors with a look-ahead chain -- a few dozen long walks per workgroup, which the drain kernel takes anyway;
+		// hundreds of cheap items (ire.descr, mp.ends.descr) are walked best where they are found.
+		// (sc->flush: it can run; use_flush(): the options of the moment want it)
+		sc->flush = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8 <= 32;
+		if( sc->flush ){
+			const size_t	budget_f = ( 160 * 1024 ) / FLUSH_WAVES_PER_SIMD - 1152;
+			sc->tile_t_flush = 0;
+			// (no larger than one pass of the workgroup's 256 lanes decodes, 32 bases a lane: profiles/flush_matrix.sh -- tiles of
+			// 7936 positions 0.639 ms, of 8192, a second pass for ten lanes, 0.757; of 10752 0.658)
+			const int	t_one = ( 254 * 32 - 61 - ( dp.w_winsize + dp.lmargin + dp.rmargin ) ) / 256 * 256;
+			for( int t = std::max( 2048, std::min( 16384, t_one ) ); t >= 2048; t -= 256 )
+				if( search_lds_bytes( sc->prog_bytes, dp, t, true, q_min, 1, true ) <= budget_f &&
+					density * t * 1.1 <= q_min + std::max( sc->spill_cap, 2 * 512 ) / 2 ){
+					sc->tile_t_flush = t;
+					break;
+				}
+			sc->qcap_flush = q_min;
+			const int	q_want_f = int( std::min( 8192.0, std::ceil( density * sc->tile_t_flush * 1.2 / 256 ) * 256 ) );
+			while( sc->tile_t_flush > 0 && sc->qcap_flush + 256 <= q_want_f &&
+				search_lds_bytes( sc->prog_bytes, dp, sc->tile_t_flush, true, sc->qcap_flush + 256, 1, true ) <= budget_f )
+				sc->qcap_flush += 256;
+			if( sc->tile_t_flush == 0 )
+				sc->flush = false;
+		}
 	}
 	if( !sc->dprog.lean_ok ){
 		// general instance: workgroups of one wave (GENERAL_BLOCK), as many per SIMD as the registers allow
@@ -483,7 +522,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 		}
 	}
 	if( sc->opt.qcap >= 64 && sc->opt.qcap <= 16384 )
-		sc->qcap = ( sc->opt.qcap + 3 ) & ~3;	// (what follows the queue in LDS is read 8 bytes at a time)
+		sc->qcap = sc->qcap_flush = ( sc->opt.qcap + 3 ) & ~3;	// (what follows the queue in LDS is read 8 bytes at a time)
 	if( sc->opt.tile > 0 )
 		sc->tile_t = sc->opt.tile;
 	// room for the candidates of a few hundred Mbase at the densities of the reference's descriptors
@@ -491,7 +530,7 @@ extern "C" int rma_scanner_create( const rma_program_t *prog, const rma_efndata_
 	// size (count-then-emit, rma_scan_end)
 	sc->hit_cap = 1 << 17;
 	HIPCHK( hipMalloc( &sc->d_hits, size_t( sc->hit_cap ) * sc->dprog.hit_stride * sizeof( int32_t ) ) );
-	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_ctr ), 4 * sizeof( unsigned long long ), hipHostMallocDefault ) );
+	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_ctr ), ( RMK_GCTL + 3 ) * sizeof( unsigned long long ), hipHostMallocDefault ) );
 	// page-locked room for the records of a usual batch (16 K of them) now, not in the first scan
 	sc->h_raw_cap = size_t( 16384 ) * sc->dprog.hit_stride;
 	HIPCHK( hipHostMalloc( reinterpret_cast<void **>( &sc->h_raw ), sc->h_raw_cap * sizeof( int32_t ), hipHostMallocDefault ) );
@@ -514,6 +553,8 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 	else if( n == "glist" ) o.glist = std::max( 0, value );
 	else if( n == "drain_waves" ) o.drain_waves = std::max( 0, value );
 	else if( n == "search_wgs" ) o.search_wgs = std::max( 0, value );
+	else if( n == "flush" ) o.flush = value;
+	else if( n == "efn_light" ) o.efn_light = value;
 	else if( n == "host_sort" ) o.host_sort = value;
 	else if( n == "timing" ) o.timing = value;
 	else if( n == "short" ) o.short_force = value;
@@ -526,7 +567,7 @@ extern "C" int rma_scanner_set_option( rma_scanner_t *sc, const char *name, int 
 		sc->last_relabelled = false;
 	}else{
 		snprintf( err, errlen, "rma_scanner_set_option: no option '%s' that can change after creation "
-			"(dbg, pool, pool_min, pool_refill, drain, glist, drain_waves, search_wgs, host_sort, timing, short; forget_last)", n.c_str() );
+			"(dbg, pool, pool_min, pool_refill, drain, glist, drain_waves, search_wgs, flush, efn_light, host_sort, timing, short; forget_last)", n.c_str() );
 		return 1;
 	}
 	return 0;
@@ -850,11 +891,21 @@ extern "C" int rma_pack_pin( rma_pack_t *pack, char *err, size_t errlen )
 
 // the pooled lean instance (see the kernel): when the window of an item, four bits a base, fits the
 // column a lane gets of the tile's place in LDS
-static bool pooled_fits( const rma_scanner_t *sc, int tile_t )
+// the pooled instance that walks nothing: where it can run (rma_scanner_create) and the options do not ask for the other one
+static bool use_flush( const rma_scanner_t *sc )
+{
+	const Options	&o = sc->opt;
+	return sc->flush && o.drain != 0 && o.pool != 0 && !( o.dbg & ( 16 | 2048 | 8388608 ) ) &&
+		( o.flush < 0 ? sc->dprog.chain.on != 0 : o.flush != 0 );
+}
+
+static bool pooled_fits( const rma_scanner_t *sc, int tile_t, bool flush = false )
 {
 	const rmd_program_t	&dp = sc->dprog;
 	if( !dp.lean_ok || ( sc->opt.dbg & 16 ) )
 		return false;
+	if( flush )		// (the instance that walks nothing lays out no window: rma_scanner_create asked what the drain kernel asks)
+		return use_flush( sc );
 	const int	tile_bytes = tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 80;
 	const int	n_dw = ( dp.w_winsize + dp.lmargin + dp.rmargin + 14 ) / 8;
 	const size_t	room = size_t( ( tile_bytes + 15 ) & ~15 ) + size_t( 6 + ( dp.chain.on ? 1 : 0 ) ) * ( ( tile_bytes + 63 ) / 64 + 3 ) * sizeof( unsigned long long );
@@ -892,6 +943,12 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 		( pooled_fits( sc, tile_t ) || !sc->dprog.lean_ok || ( sc->opt.dbg & 16 ) ) && !sc->dprog.wide;		// (the pooled lean instance, or a general one)
 	if( concat )
 		grouped = false;
+	// (long entries, a descriptor with a look-ahead chain: the instance that walks nothing, on tiles of its own size)
+	const bool	flush = use_flush( sc ) && !concat && !grouped;
+	if( flush ){
+		tile_t = sc->opt.tile > 0 ? sc->opt.tile : sc->tile_t_flush;
+		qcap = sc->qcap_flush;
+	}
 	if( grouped && sc->dprog.lean_ok && !( sc->opt.dbg & 16 ) ){
 		const size_t	budget = ( 160 * 1024 ) / SEARCH_WAVES_PER_SIMD - 64 - SHORT_GROUP * 32;
 		// (tiles of 1024 positions measured slower than of 768 where both fit: mp.ends 1.56 / 1.40 ms)
@@ -910,7 +967,7 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	const int	strands = sc->prog.chk_both_strs ? 2 : 1, dminlen = sc->prog.dminlen;
 	std::lock_guard<std::mutex>	lk( db->mu );
 	for( auto &l : db->layouts )
-		if( l->tile_t == tile_t && l->dminlen == dminlen && l->strands == strands && l->group == group && l->qcap == qcap && l->concat == concat )
+		if( l->tile_t == tile_t && l->dminlen == dminlen && l->strands == strands && l->group == group && l->qcap == qcap && l->concat == concat && l->flush == flush )
 			return l.get();
 	std::unique_ptr<Layout>	l( new Layout );
 	l->tile_t = tile_t;
@@ -919,6 +976,7 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	l->group = group;
 	l->qcap = qcap;
 	l->concat = concat;
+	l->flush = flush;
 	l->concat_bases = db->padded_bases;
 	std::vector<int64_t>	&tile_start = l->h_tile_start;
 	tile_start.assign( size_t( n ) + 1, 0 );
@@ -1055,9 +1113,10 @@ static int launch_search( rma_scanner_t *sc, char *err, size_t errlen )
 	a.prog_bytes = sc->prog_bytes;
 	a.qcap = f.lay->qcap;
 	a.db = view_of( f.db, f.lay );
-	const bool	drain = ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0;
+	const bool	listed = f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT || f.inst == RMK_LEAN_FLUSH;
+	const bool	drain = listed && sc->glist_cap > 0;
 	a.hb = HitBuf{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap, sc->d_pool, sc->pool_cap,
-		sc->opt.pool_min, sc->opt.pool_refill, ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) ? sc->glist_cap : 0 };
+		sc->opt.pool_min, sc->opt.pool_refill, listed ? sc->glist_cap : 0 };
 	a.tile_bytes = f.tile_bytes;
 	a.dbg = sc->opt.dbg | ( sc->whole_items ? 2097152 : 0 );
 	HIPCHK( hipEventRecord( sc->ev[ 0 ], sc->stream ) );
@@ -1071,8 +1130,9 @@ static int launch_search( rma_scanner_t *sc, char *err, size_t errlen )
 		HIPCHK( rmk_launch_lean_drain( sc->drain_grid, sc->drain_lds, sc->stream, a ) );
 	}
 	HIPCHK( hipEventRecord( sc->ev[ 1 ], sc->stream ) );
-	// [0] candidates, [3] queue overflow of the general instance: one copy, one wait
-	HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->d_counters, 4 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, sc->stream ) );
+	// [0] candidates, [3] queue overflow of the general instance, [RMK_GCTL] items reserved in the drain kernel's list,
+	// [RMK_GCTL + 2] queue overflow of the lean instance that walks nothing: one copy, one wait
+	HIPCHK( hipMemcpyAsync( sc->h_ctr, sc->d_counters, ( RMK_GCTL + 3 ) * sizeof( unsigned long long ), hipMemcpyDeviceToHost, sc->stream ) );
 	return 0;
 }
 
@@ -1100,11 +1160,12 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 			tot += double( ph[ i ] );
 		unsigned long long	lv[ 80 ];
 		( void )hipMemcpy( lv, sc->d_counters + 16, sizeof( lv ), hipMemcpyDeviceToHost );
-		if( f.lean && !( ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0 ) )
+		const bool	listed = f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT || f.inst == RMK_LEAN_FLUSH;
+		if( f.lean && !( listed && sc->glist_cap > 0 ) )
 			fprintf( stderr, "[dbg] pool sessions: %.3g wave cycles popping (%.0f per round), %.3g stepping (%.0f per step)\n",
 				double( lv[ 4 ] ), lv[ 0 ] ? double( lv[ 4 ] ) / lv[ 0 ] : 0.0, double( lv[ 5 ] ), lv[ 2 ] ? double( lv[ 5 ] ) / lv[ 2 ] : 0.0 ),
 			fprintf( stderr, "[dbg] longest step %.3g cycles, most stepping in one wave (one session) %.3g cycles\n", double( lv[ 6 ] ), double( lv[ 7 ] ) );
-		if( ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0 ){
+		if( listed && sc->glist_cap > 0 ){
 			// (the drain kernel's items)
 			unsigned long long	g[ 2 ];
 			( void )hipMemcpy( g, sc->d_counters + RMK_GCTL, sizeof( g ), hipMemcpyDeviceToHost );
@@ -1131,7 +1192,7 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 					fprintf( stderr, " %d:%llu,%.0f", kk, lv[ 61 + kk ], double( lv[ 45 + kk ] ) / lv[ 61 + kk ] );
 			fprintf( stderr, "\n" );
 		}
-		if( f.lean && !( ( f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT ) && sc->glist_cap > 0 ) )
+		if( f.lean && !( listed && sc->glist_cap > 0 ) )
 			fprintf( stderr, "[dbg] pass B: %llu pop rounds of %.1f lanes, %llu steps of %.1f lanes; wave cycles popping %.1f%%, stepping %.1f%%\n",
 				lv[ 0 ], lv[ 0 ] ? double( lv[ 1 ] ) / lv[ 0 ] : 0.0, lv[ 2 ], lv[ 2 ] ? double( lv[ 3 ] ) / lv[ 2 ] : 0.0,
 				100.0 * lv[ 4 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ), 100.0 * lv[ 5 ] / double( lv[ 4 ] + lv[ 5 ] + 1 ) );
@@ -1190,14 +1251,14 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	f.lean = dp.lean_ok && !( sc->opt.dbg & 16 );
 	f.grouped = f.lean && lay->group > 1;
 	f.tile_bytes = lay->tile_t + dp.w_winsize + dp.lmargin + dp.rmargin + 80;
-	f.lds = search_lds_bytes( sc->prog_bytes, dp, lay->tile_t, f.lean, lay->qcap, f.grouped ? SHORT_GROUP : 1 );
+	f.lds = search_lds_bytes( sc->prog_bytes, dp, lay->tile_t, f.lean, lay->qcap, f.grouped ? SHORT_GROUP : 1, f.lean && lay->flush );
 	if( f.lds > 150 * 1024 ){
 		snprintf( err, errlen, "window of %d bases does not fit the LDS tile (%zu bytes needed)", dp.w_winsize, f.lds );
 		return 1;
 	}
 	// the pooled lean instance (see the kernel): when the window of an item, four bits a base, fits the
 	// column a lane gets of the tile's place in LDS
-	const bool	pooled = f.lean && !f.grouped && pooled_fits( sc, lay->tile_t );
+	const bool	pooled = f.lean && !f.grouped && pooled_fits( sc, lay->tile_t, lay->flush );
 	if( lay->concat && f.lean && !pooled ){
 		snprintf( err, errlen, "a tiling over the concatenation of the entries is for the pooled lean instance and the general ones" );	// (layout_for asks pooled_fits too)
 		return 1;
@@ -1205,10 +1266,12 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	if( pooled ){
 		// The list of the drain kernel: room for an item per 32 bases (trna.descr leaves one per 70 before the
 		// stem-loop tests and one per 4500 after them); a workgroup that finds it full walks its own items.
-		const int	want = !sc->opt.drain ? 0 : sc->opt.glist > 0 ? sc->opt.glist :
+		int	want = !sc->opt.drain ? 0 : sc->opt.glist > 0 ? sc->opt.glist :
 			int( std::min<long long>( std::max<long long>( db->sum_slen / 32, 1 << 18 ), 1 << 24 ) );
+		if( lay->flush )		// (what an earlier scan reserved beyond the list's end: search_finish)
+			want = std::max( want, sc->glist_need );
 		const int	cap = sc->opt.pool_min + lay->qcap + sc->spill_cap;
-		if( cap > sc->pool_cap || want > sc->glist_cap || ( want == 0 && sc->glist_cap != 0 ) || ( sc->opt.glist > 0 && want != sc->glist_cap ) ){
+		if( cap > sc->pool_cap || want > sc->glist_cap || ( want == 0 && sc->glist_cap != 0 ) || ( sc->opt.glist > 0 && want != sc->glist_cap && !lay->flush ) ){
 			HIPCHK( hipStreamSynchronize( sc->stream ) );
 			( void )hipFree( sc->d_pool );
 			sc->d_pool = nullptr;
@@ -1226,7 +1289,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	}
 	// the kernel instance: lean (pooled, one tile or a group of small ones per pass), or the general one
 	// compiled for the kinds of element the descriptor has
-	f.inst = pooled ? ( lay->concat ? RMK_LEAN_CONCAT : RMK_LEAN_POOL ) : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
+	f.inst = pooled ? ( lay->concat ? RMK_LEAN_CONCAT : lay->flush ? RMK_LEAN_FLUSH : RMK_LEAN_POOL ) : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
 		dp.wide ? RMK_GEN_WIDE :
 		lay->concat ? ( sc->kinds == 0 ? RMK_GEN_PLAIN_CONCAT : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK_CONCAT : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ_CONCAT : RMK_GEN_PKTQ_CONCAT ) :
 		sc->kinds == 0 ? RMK_GEN_PLAIN : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ : RMK_GEN_PKTQ;
@@ -1234,6 +1297,12 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	f.grid = int( std::min<int64_t>( n_units, f.lean ? sc->grid_blocks : sc->spill_blocks ) );
 	if( f.lean && sc->opt.search_wgs > 0 )		// (option search_wgs: workgroups of a lean search kernel per CU -- room for another scanner's drain kernel beside it)
 		f.grid = std::min( f.grid, sc->opt.search_wgs * ( sc->grid_blocks / 8 ) );
+	else if( f.inst == RMK_LEAN_FLUSH )
+		// The instance that walks nothing is compiled for five workgroups a CU (96 registers, a fifth of the LDS) and runs
+		// four: a fifth measures the same (0.642 against 0.639 ms), and what it would take -- 33 KB of LDS, a wave's registers
+		// on every SIMD -- is where the drain kernel and the energy kernel of the scanner that had the step before run
+		// meanwhile (two scanners in turns).
+		f.grid = std::min( f.grid, FLUSH_WGS_PER_CU * ( sc->grid_blocks / 8 ) );
 	// the database's upload and the tiling's, on the device's upload stream, come first
 	HIPCHK( hipStreamWaitEvent( sc->stream, db->ready, 0 ) );
 	HIPCHK( hipStreamWaitEvent( sc->stream, lay->ready, 0 ) );
@@ -1271,6 +1340,37 @@ static int search_finish( rma_scanner_t *sc, int64_t *n_hits, float *search_ms, 
 				sc->d_spill = nullptr;
 				sc->spill_cap = int( need ) + 1024;
 				HIPCHK( hipMalloc( &sc->d_spill, size_t( sc->spill_blocks ) * sc->spill_cap * sizeof( unsigned ) ) );
+				again = true;
+			}
+		}
+		if( f.inst == RMK_LEAN_FLUSH ){
+			// the instance that walks nothing reports what it had no room for -- a tile's items beyond queue and spill area, the
+			// list's items beyond its end -- and the scan is repeated with room for them
+			const unsigned long long	q_need = sc->h_ctr[ RMK_GCTL + 2 ], l_need = sc->h_ctr[ RMK_GCTL ];
+			if( ( q_need > 0 || l_need > ( unsigned long long )sc->glist_cap ) && attempt == 3 ){
+				snprintf( err, errlen, "work queue or item list overflow after regrow (%llu items in a tile, %llu in the list)", q_need, l_need );
+				return 1;
+			}
+			if( q_need > 0 ){
+				( void )hipFree( sc->d_spill );
+				sc->d_spill = nullptr;
+				sc->spill_cap = int( q_need ) + 1024;
+				HIPCHK( hipMalloc( &sc->d_spill, size_t( sc->spill_blocks ) * sc->spill_cap * sizeof( unsigned ) ) );
+				again = true;
+			}
+			if( l_need > ( unsigned long long )sc->glist_cap ){
+				if( l_need > ( 1ull << 28 ) ){
+					snprintf( err, errlen, "%llu items for the drain kernel's list: more than it can be made to hold", l_need );
+					return 1;
+				}
+				( void )hipFree( sc->d_pool );
+				sc->d_pool = nullptr;
+				sc->glist_need = int( l_need + l_need / 8 ) + 1024;
+				const int	cap1 = sc->pool_cap;
+				sc->pool_cap = sc->glist_cap = 0;
+				HIPCHK( hipMalloc( &sc->d_pool, ( size_t( sc->glist_need ) + size_t( sc->grid_blocks ) * cap1 ) * RMK_POOL_WORDS * sizeof( unsigned ) ) );
+				sc->pool_cap = cap1;
+				sc->glist_cap = sc->glist_need;
 				again = true;
 			}
 		}
@@ -1314,6 +1414,12 @@ static int launch_efn( rma_scanner_t *sc, int64_t count, char *err, size_t errle
 		sc->have_efn ? sc->d_t16 : nullptr, sc->d_tlkey, sc->d_loginc, sc->d_efn2 };
 	sc->efn_ran = true;
 	HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
+	// (behind the search instance that walks nothing: workgroups of one wave that find room next to another scanner's search
+	// kernel -- the staged form's 136 KB of LDS wait until that kernel is through)
+	const bool	light = !sc->dprog.efn_big && ( sc->opt.efn_light < 0 ? sc->fly.inst == RMK_LEAN_FLUSH : sc->opt.efn_light != 0 );
+	if( light )
+		HIPCHK( rmk_launch_efn_light( int( std::min<int64_t>( ( count + 63 ) / 64, sc->grid_blocks * 2 ) ), sc->stream, a ) );
+	else
 	HIPCHK( sc->dprog.efn_big ? rmk_launch_efn_big( int( blocks ), sc->stream, a ) : rmk_launch_efn( int( blocks ), sc->stream, a ) );
 	HIPCHK( hipEventRecord( sc->ev[ 3 ], sc->stream ) );
 	return 0;

@@ -230,6 +230,40 @@ def test_pooled_and_tile_by_tile_pass_b_agree(built, workdir, gbrna, name):
     assert 0 < ref.shape[0] <= want.shape[0] or want.shape[0] == 0
 
 
+@pytest.mark.parametrize("name", ["trna.descr", "bulge.descr", "ire.descr", "mp.ends.descr"])
+def test_search_kernel_that_walks_nothing(built, workdir, gbrna, name):
+    """RMK_LEAN_FLUSH (round 4; option `flush`: by default where the descriptor has a look-ahead chain): every survivor of
+    pass A' goes to the drain kernel's list, the search kernel keeps no pool and walks nothing.  What has no room -- a tile's
+    items beyond queue and spill area, the list's items beyond its end -- is reported and the scan repeated with room for
+    it (search_finish), where the other pooled instance searches in place.  Records equal to the oracle's with the
+    instance forced on and off, a list of one item, a queue of 64 and no spill area, small tiles, and the energy kernel
+    in both its forms."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(47)
+    lut = np.frombuffer(b"acgtn", dtype=np.uint8)
+    seqs = [lut[rng.integers(0, 4, size=n)].tobytes() for n in (300_007, 61, 7, 40_000)]
+    seqs.append(lut[rng.choice(5, size=30_000, p=[.22, .22, .22, .22, .12])].tobytes())
+    seqs += [b"".join(r[2] for r in R.read_fasta(gbrna)[:300])]        # (one long entry of real RNA: clustered survivors)
+    d = _descr(workdir, name)
+    want = oracle_scan(d, seqs)
+    assert want.shape[0] > 0 or name == "ire.descr"
+    for env in ({}, {"RNAMOTIF_QCAP": "64", "RNAMOTIF_SPILL": "0"}, {"RNAMOTIF_TILE": "512", "RNAMOTIF_QCAP": "64", "RNAMOTIF_SPILL": "16"}):
+        with _env(RNAMOTIF_SHORT="0", **env):
+            sc = R.Scanner(d)
+            db = sc.database(seqs)
+            for opts in ({"flush": 1}, {"flush": 0}, {"flush": -1}, {"flush": 1, "glist": 1}, {"flush": 1, "efn_light": 0},
+                         {"flush": 0, "efn_light": 1}, {"flush": 1, "dbg": 2097152}, {"flush": 1, "dbg": 4194304}):
+                for k, v in dict({"flush": -1, "glist": 0, "efn_light": -1, "dbg": 0}, **opts).items():
+                    sc.set_option(k, v)
+                got = sc.scan(db)
+                assert got.shape == want.shape and np.array_equal(got, want), (env, opts)
+                # (a second scan: the areas the first one had to grow are there now)
+                assert np.array_equal(sc.scan(db), want), (env, opts)
+            db.close()
+            sc.close()
+
+
 def test_tile_sizes_agree(built, workdir):
     """Tile size is a launch parameter only: 256..8192 start positions per
     workgroup give identical records."""
