@@ -109,6 +109,7 @@ enum rmk_instance {
 	RMK_LEAN_POOL = 0,	// lean, pass B over a pool of survivors (the headline instance)
 	RMK_LEAN_CONCAT,	// ... with the tiles over the concatenation of the entries (databases of short entries)
 	RMK_LEAN_FLUSH,		// lean, every survivor of pass A' straight to the drain kernel's list: the search kernel walks nothing
+	RMK_LEAN_CONCAT_FLUSH,	// ... with the tiles over the concatenation of the entries
 	RMK_LEAN_GROUP,		// lean, groups of SHORT_GROUP small tiles (databases of short entries)
 	RMK_LEAN_TILE,		// lean, pass B tile by tile
 	RMK_GEN_PLAIN,		// general, no pseudoknot, no triplex / 4-plex
@@ -137,6 +138,7 @@ hipError_t	rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 hipError_t	rmk_launch_lean_pool( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_concat( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_flush( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
+hipError_t	rmk_launch_lean_concat_flush( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_drain( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );	// (qcap: not used; tile_bytes: window dwords per lane)
 hipError_t	rmk_launch_lean_group( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );
 hipError_t	rmk_launch_lean_tile( int grid, size_t lds, hipStream_t s, const rmk_search_args &a );

@@ -299,6 +299,7 @@ hipError_t rmk_launch_search( int inst, int grid, size_t lds, hipStream_t s, con
 	case RMK_LEAN_POOL :	return rmk_launch_lean_pool( grid, lds, s, a );
 	case RMK_LEAN_CONCAT :	return rmk_launch_lean_concat( grid, lds, s, a );
 	case RMK_LEAN_FLUSH :	return rmk_launch_lean_flush( grid, lds, s, a );
+	case RMK_LEAN_CONCAT_FLUSH :	return rmk_launch_lean_concat_flush( grid, lds, s, a );
 	case RMK_LEAN_GROUP :	return rmk_launch_lean_group( grid, lds, s, a );
 	case RMK_LEAN_TILE :	return rmk_launch_lean_tile( grid, lds, s, a );
 	case RMK_GEN_PLAIN :	return rmk_launch_gen_plain( grid, lds, s, a );
@@ -944,7 +945,7 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 	if( concat )
 		grouped = false;
 	// (long entries, a descriptor with a look-ahead chain: the instance that walks nothing, on tiles of its own size)
-	const bool	flush = use_flush( sc ) && !concat && !grouped;
+	const bool	flush = use_flush( sc ) && !grouped;
 	if( flush ){
 		tile_t = sc->opt.tile > 0 ? sc->opt.tile : sc->tile_t_flush;
 		qcap = sc->qcap_flush;
@@ -1113,7 +1114,7 @@ static int launch_search( rma_scanner_t *sc, char *err, size_t errlen )
 	a.prog_bytes = sc->prog_bytes;
 	a.qcap = f.lay->qcap;
 	a.db = view_of( f.db, f.lay );
-	const bool	listed = f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT || f.inst == RMK_LEAN_FLUSH;
+	const bool	listed = f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT || f.inst == RMK_LEAN_FLUSH || f.inst == RMK_LEAN_CONCAT_FLUSH;
 	const bool	drain = listed && sc->glist_cap > 0;
 	a.hb = HitBuf{ sc->d_hits, sc->d_counters, sc->d_counters + 1, sc->hit_cap, sc->d_spill, sc->spill_cap, sc->d_pool, sc->pool_cap,
 		sc->opt.pool_min, sc->opt.pool_refill, listed ? sc->glist_cap : 0 };
@@ -1160,7 +1161,7 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 			tot += double( ph[ i ] );
 		unsigned long long	lv[ 80 ];
 		( void )hipMemcpy( lv, sc->d_counters + 16, sizeof( lv ), hipMemcpyDeviceToHost );
-		const bool	listed = f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT || f.inst == RMK_LEAN_FLUSH;
+		const bool	listed = f.inst == RMK_LEAN_POOL || f.inst == RMK_LEAN_CONCAT || f.inst == RMK_LEAN_FLUSH || f.inst == RMK_LEAN_CONCAT_FLUSH;
 		if( f.lean && !( listed && sc->glist_cap > 0 ) )
 			fprintf( stderr, "[dbg] pool sessions: %.3g wave cycles popping (%.0f per round), %.3g stepping (%.0f per step)\n",
 				double( lv[ 4 ] ), lv[ 0 ] ? double( lv[ 4 ] ) / lv[ 0 ] : 0.0, double( lv[ 5 ] ), lv[ 2 ] ? double( lv[ 5 ] ) / lv[ 2 ] : 0.0 ),
@@ -1289,7 +1290,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	}
 	// the kernel instance: lean (pooled, one tile or a group of small ones per pass), or the general one
 	// compiled for the kinds of element the descriptor has
-	f.inst = pooled ? ( lay->concat ? RMK_LEAN_CONCAT : lay->flush ? RMK_LEAN_FLUSH : RMK_LEAN_POOL ) : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
+	f.inst = pooled ? ( lay->concat ? ( lay->flush ? RMK_LEAN_CONCAT_FLUSH : RMK_LEAN_CONCAT ) : lay->flush ? RMK_LEAN_FLUSH : RMK_LEAN_POOL ) : f.grouped ? RMK_LEAN_GROUP : f.lean ? RMK_LEAN_TILE :
 		dp.wide ? RMK_GEN_WIDE :
 		lay->concat ? ( sc->kinds == 0 ? RMK_GEN_PLAIN_CONCAT : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK_CONCAT : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ_CONCAT : RMK_GEN_PKTQ_CONCAT ) :
 		sc->kinds == 0 ? RMK_GEN_PLAIN : sc->kinds == RMD_KIND_PK ? RMK_GEN_PK : sc->kinds == RMD_KIND_TQ ? RMK_GEN_TQ : RMK_GEN_PKTQ;
@@ -1297,7 +1298,7 @@ extern "C" int rma_scan_begin( rma_scanner_t *sc, const rma_db_t *db, char *err,
 	f.grid = int( std::min<int64_t>( n_units, f.lean ? sc->grid_blocks : sc->spill_blocks ) );
 	if( f.lean && sc->opt.search_wgs > 0 )		// (option search_wgs: workgroups of a lean search kernel per CU -- room for another scanner's drain kernel beside it)
 		f.grid = std::min( f.grid, sc->opt.search_wgs * ( sc->grid_blocks / 8 ) );
-	else if( f.inst == RMK_LEAN_FLUSH )
+	else if( f.inst == RMK_LEAN_FLUSH || f.inst == RMK_LEAN_CONCAT_FLUSH )
 		// The instance that walks nothing is compiled for five workgroups a CU (96 registers, a fifth of the LDS) and runs
 		// four: a fifth measures the same (0.642 against 0.639 ms), and what it would take -- 33 KB of LDS, a wave's registers
 		// on every SIMD -- is where the drain kernel and the energy kernel of the scanner that had the step before run
@@ -1343,7 +1344,7 @@ static int search_finish( rma_scanner_t *sc, int64_t *n_hits, float *search_ms, 
 				again = true;
 			}
 		}
-		if( f.inst == RMK_LEAN_FLUSH ){
+		if( f.inst == RMK_LEAN_FLUSH || f.inst == RMK_LEAN_CONCAT_FLUSH ){
 			// the instance that walks nothing reports what it had no room for -- a tile's items beyond queue and spill area, the
 			// list's items beyond its end -- and the scan is repeated with room for them
 			const unsigned long long	q_need = sc->h_ctr[ RMK_GCTL + 2 ], l_need = sc->h_ctr[ RMK_GCTL ];
@@ -1416,7 +1417,7 @@ static int launch_efn( rma_scanner_t *sc, int64_t count, char *err, size_t errle
 	HIPCHK( hipEventRecord( sc->ev[ 2 ], sc->stream ) );
 	// (behind the search instance that walks nothing: workgroups of one wave that find room next to another scanner's search
 	// kernel -- the staged form's 136 KB of LDS wait until that kernel is through)
-	const bool	light = !sc->dprog.efn_big && ( sc->opt.efn_light < 0 ? sc->fly.inst == RMK_LEAN_FLUSH : sc->opt.efn_light != 0 );
+	const bool	light = !sc->dprog.efn_big && ( sc->opt.efn_light < 0 ? ( sc->fly.inst == RMK_LEAN_FLUSH || sc->fly.inst == RMK_LEAN_CONCAT_FLUSH ) : sc->opt.efn_light != 0 );
 	if( light )
 		HIPCHK( rmk_launch_efn_light( int( std::min<int64_t>( ( count + 63 ) / 64, sc->grid_blocks * 2 ) ), sc->stream, a ) );
 	else

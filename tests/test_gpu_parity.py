@@ -307,9 +307,12 @@ def test_grouped_tiles_agree(built, workdir, gbrna, name):
         res = []
         # ("2": tiles over the concatenation of the entries -- round 4, the pooled lean instance; the queue of 64 with a spill
         # area of 0 / 32 items sends items through the search in place, from the tile's bytes in their entry's coordinates)
-        for short, qcap, spill in (("0", None, None), ("1", None, None), ("1", 64, None), ("1", 64, 0), ("0", 64, 32),
-                                   ("2", None, None), ("2", 64, 32), ("2", 64, 0)):
-            with _env(RNAMOTIF_SHORT=short, RNAMOTIF_QCAP=qcap, RNAMOTIF_SPILL=spill):
+        # (RNAMOTIF_FLUSH: the pooled instance that walks nothing, forced off and on -- by default descriptors with a look-ahead
+        # chain take it; what its queue and spill area do not hold makes the scan repeat with room for it)
+        for short, qcap, spill, flush in (("0", None, None, None), ("1", None, None, None), ("1", 64, None, None), ("1", 64, 0, None),
+                                          ("0", 64, 32, None), ("2", None, None, None), ("2", 64, 32, None), ("2", 64, 0, None),
+                                          ("2", None, None, "0"), ("2", 64, 0, "0"), ("2", None, None, "1"), ("2", 64, 0, "1"), ("0", 64, 0, "1")):
+            with _env(RNAMOTIF_SHORT=short, RNAMOTIF_QCAP=qcap, RNAMOTIF_SPILL=spill, RNAMOTIF_FLUSH=flush):
                 sc = R.Scanner(d)
                 res.append(sc.scan(sc.database(seqs)))
         assert res[0].shape[0] > 0 or not check_oracle or name in ("ire.descr", "pk_j1+2.descr", "qu+tr.descr", "nanlin.descr")
