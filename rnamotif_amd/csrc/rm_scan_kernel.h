@@ -799,6 +799,9 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 	const int	fair = share < 1 ? 1 : share > 64 ? 64 : int( share );
 	const int	refill = rmd_imax( 1, rmd_imin( hb.pool_refill, fair / 2 ) );
 	rmd_nibseq_t<BLOCK>	nsq{ col, 0, 0 };
+	// (the lane whose column holds this lane's window: its own, or -- a subtree it was handed -- the one it came from)
+	int	wlane = lane_id;
+	const uint32_t	*const col0 = col - tid;
 	rmd_lean_t	st;
 	DevSink	sink{ hb, 0, 0, P->hit_stride };
 	const rmd_no_accel_t	none;
@@ -812,6 +815,14 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 		// lanes that came free take items once enough of them have (a round costs the wave the same for one
 		// lane as for sixteen), and no more than leaves the other waves their share
 		const int	n = rmd_imin( __popcll( want ), fair - __popcll( busy ) );
+		// (diagnostic, RNAMOTIF_DBG bit 32: the wave's cycles by what it does -- taking items, stepping, complete matches, hand-overs)
+		unsigned long long	t_d0 = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
+#define DRAIN_LAP( slot_ )	do{ if( dbg & 32 ){ \
+			const unsigned long long	now_ = __builtin_amdgcn_s_memtime(); \
+			if( lane_id == 0 ) \
+				atomicAdd( hb.ticket + ( slot_ ), now_ - t_d0 ); \
+			t_d0 = now_; \
+		} }while( 0 )
 		if( n > 0 && ( busy == 0 || n >= refill ) ){
 			unsigned long long	base = 0;
 			if( lane_id == __ffsll( want ) - 1 )
@@ -824,6 +835,8 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 					// (a workgroup whose items found no room in the list left its share of it void)
 					if( __hip_atomic_load( e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) != 0xffffffffu ){
 						k = pool_item_begin<BLOCK>( P, db, e, col, n_nib, lr, st, nsq, sink.seq, sink.comp, obase );
+						nsq.w = col;
+						wlane = lane_id;
 						floor_ = 0;
 						t_item = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
 						n_steps = n_emit = 0;
@@ -831,20 +844,27 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 				}else if( ( long long )base + n >= total )
 					dry = true;
 			}
+			DRAIN_LAP( 94 );
 			continue;
 		}
 		if( busy == 0 )
 			break;
 		const bool	was = k >= 0;
 		const int	k_was = k;
+		if( ( dbg & 32 ) && lane_id == 0 ){
+			atomicAdd( hb.ticket + 98, 1ull );
+			atomicAdd( hb.ticket + 93, ( unsigned long long )__popcll( busy ) );
+		}
 		if( k >= 0 ){
 			k = rmd_lean_step<LdsRecs<BLOCK>, DevSink, rmd_nibseq_t<BLOCK>, rmd_no_accel_t, true>( P, lr, st, nsq, k, nullptr, sink, none );
 			n_steps++;
 			n_emit += st.pending;
 		}
+		DRAIN_LAP( 95 );
 		wave_emit_pending<BLOCK, true>( P, lr, st, k, [ & ]( int l ){
-			return rmd_nibseq_t<BLOCK>{ nsq.w + ( l - lane_id ), __shfl( nsq.flip, l ), __shfl( nsq.bias, l ) }; },
+			return rmd_nibseq_t<BLOCK>{ col0 + __shfl( wlane, l ), __shfl( nsq.flip, l ), __shfl( nsq.bias, l ) }; },
 			sink.seq, sink.comp, hb, lane_id, obase );
+		DRAIN_LAP( 96 );
 		if( k >= 0 && k < floor_ )
 			k = -1;		// (the subtree this lane was given is done)
 		if( forks ){
@@ -884,16 +904,29 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 				sink.seq = __shfl( sink.seq, src );
 				sink.comp = __shfl( sink.comp, src );
 				obase = __shfl( obase, src );
+				// The window is not copied: the taker reads it where it lies.  (A lane is idle for good -- `dry` -- only once the list's
+				// counter has passed its end, and from then on no lane of any wave begins an item: the columns stay as they are.)
+				wlane = __shfl( wlane, src );
+				nsq.w = col0 + wlane;
 				if( taker ){
+					// the records, four levels' loads ahead of their stores (the two may be the same LDS for all the compiler knows)
 					const uint32_t	*lo_s = lr.lo + ( src - lane_id );
 					const uint16_t	*hi_s = lr.hi + ( src - lane_id );
-					for( int j = 0; j < P->n_searches; j++ ){
-						lr.lo[ j * BLOCK ] = lo_s[ j * BLOCK ];
-						lr.hi[ j * BLOCK ] = hi_s[ j * BLOCK ];
+					const int	ns = P->n_searches;
+					for( int j = 0; j < ns; j += 4 ){
+						uint32_t	a[ 4 ];
+						uint16_t	b[ 4 ];
+						for( int q = 0; q < 4; q++ ){
+							const int	jq = rmd_imin( j + q, ns - 1 );
+							a[ q ] = lo_s[ jq * BLOCK ];
+							b[ q ] = hi_s[ jq * BLOCK ];
+						}
+						for( int q = 0; q < 4; q++ )
+							if( j + q < ns ){
+								lr.lo[ ( j + q ) * BLOCK ] = a[ q ];
+								lr.hi[ ( j + q ) * BLOCK ] = b[ q ];
+							}
 					}
-					const uint32_t	*col_s = col + ( src - lane_id );
-					for( int j = 0; j < n_nib; j++ )
-						col[ j * BLOCK ] = col_s[ j * BLOCK ];
 					st.pending = 0;
 					k = k_src;
 					floor_ = k_src;
@@ -904,6 +937,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 					k = k_was;	// (back at its own level, the subtree below as good as walked)
 			}
 		}
+		DRAIN_LAP( 97 );
 		if( ( dbg & 32 ) && was && k < 0 ){
 			// (diagnostic: how long the items take, how many steps, how many complete matches)
 			const unsigned long long	dt = __builtin_amdgcn_s_memtime() - t_item;
@@ -917,6 +951,7 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 			atomicAdd( hb.ticket + 76 + rmd_imin( 31 - __clz( n_emit | 1 ) + ( n_emit > 0 ), 15 ), dt );
 		}
 	}
+#undef DRAIN_LAP
 }
 
 // ---------------------------------------------------------------- search kernel

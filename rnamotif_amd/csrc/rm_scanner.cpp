@@ -1172,6 +1172,14 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 			( void )hipMemcpy( g, sc->d_counters + RMK_GCTL, sizeof( g ), hipMemcpyDeviceToHost );
 			fprintf( stderr, "[dbg] drain: %llu items in the list (%llu taken), %llu walked: %.0f cycles and %.1f steps each; longest %.3g cycles, most steps %llu\n",
 				g[ 0 ], g[ 1 ], lv[ 2 ], lv[ 2 ] ? double( lv[ 5 ] ) / lv[ 2 ] : 0.0, lv[ 2 ] ? double( lv[ 3 ] ) / lv[ 2 ] : 0.0, double( lv[ 6 ] ), lv[ 7 ] );
+			{
+				unsigned long long	lap[ 6 ];
+				( void )hipMemcpy( lap, sc->d_counters + 1 + 93, sizeof( lap ), hipMemcpyDeviceToHost );
+				const double	all = double( lap[ 1 ] + lap[ 2 ] + lap[ 3 ] + lap[ 4 ] ) + 1;
+				fprintf( stderr, "[dbg] drain: %llu wave rounds of %.1f lanes; wave cycles taking items %.1f%%, stepping %.1f%%, complete matches %.1f%%, hand-overs %.1f%%; %.0f cycles a round\n",
+					lap[ 5 ], lap[ 5 ] ? double( lap[ 0 ] ) / lap[ 5 ] : 0.0, 100 * lap[ 1 ] / all, 100 * lap[ 2 ] / all, 100 * lap[ 3 ] / all, 100 * lap[ 4 ] / all,
+					lap[ 5 ] ? all / lap[ 5 ] : 0.0 );
+			}
 			fprintf( stderr, "[dbg] drain: items by log2( cycles ):" );
 			for( int b = 8; b < 32; b++ )
 				if( lv[ 8 + b ] )
