@@ -62,7 +62,7 @@ int	rma_scanner_create( const rma_program_t *prog, const rma_efndata_t *efn, int
 int	rma_scanner_set_efn2data( rma_scanner_t *sc, const rma_efn2data_t *efn2, char *err, size_t errlen );
 /* Launch-shape and diagnostic switches (DESIGN.md has the table).  The RNAMOTIF_* environment is read
  * once, by rma_scanner_create(); the switches that may change between scans change through this call
- * only: "dbg", "pool", "pool_min", "pool_refill", "drain", "glist", "drain_waves", "search_wgs", "host_sort", "timing", "short".
+ * only: "dbg", "pool", "pool_min", "pool_refill", "drain", "glist", "drain_waves", "search_wgs", "flush", "efn_light", "host_sort", "timing", "short".
  * None of them changes the records a scan returns. */
 int	rma_scanner_set_option( rma_scanner_t *sc, const char *name, int value, char *err, size_t errlen );
 /* One scan of eight start positions, thrown away: what the runtime sets up on first use (code objects,

@@ -19,6 +19,8 @@ done
 python3 $R/bench.py --steps 5 --warmup 1 --cpu-bases 0 --records 1000 --descr $T/qu+tr.descr,$T/mp.ends.descr 2> /dev/null | grep '^{"metric"' > $R/gpurun_out/r4c/cfg_mixed_1G.json
 python3 $R/profiles/step_breakdown.py > $R/gpurun_out/r4c/step_breakdown.txt 2>&1
 python3 $R/profiles/lean_stages.py trna.descr mp.ends.descr ire.1.descr 2>&1 | grep '^==' > $R/gpurun_out/r4c/lean_stages.txt
+python3 $R/profiles/flush_stages.py 2> /dev/null | grep '^==' > $R/gpurun_out/r4c/flush_stages_now.txt
+python3 $R/profiles/drain_stats.py 2>&1 | grep -v 'wave cycles: ' > $R/gpurun_out/r4c/drain_stats.txt
 python3 $R/profiles/gen_counts.py > $R/gpurun_out/r4c/gen_counts.txt 2>&1
 python3 $R/profiles/phases.py trna.descr > $R/gpurun_out/r4c/trna_phases.txt 2>&1
 python3 $R/profiles/quick_times.py --real > $R/gpurun_out/r4c/quick_times.txt 2>&1
