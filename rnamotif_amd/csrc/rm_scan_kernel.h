@@ -809,6 +809,9 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 	const bool	forks = P->ord_ok && !( dbg & 4194304 );
 	unsigned long long	t_item = 0;
 	bool	dry = total == 0;
+	// (diagnostic, RNAMOTIF_DBG bit 536870912: when the waves are through, in bins of 16 us from the first wave's start)
+	if( ( dbg & 536870912 ) && lane_id == 0 )
+		atomicMax( hb.ticket + 55, ~( unsigned long long )wall_clock64() );
 	for( ; ; ){
 		const unsigned long long	want = __ballot( k < 0 && !dry );
 		const unsigned long long	busy = __ballot( k >= 0 );
@@ -838,6 +841,8 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 						nsq.w = col;
 						wlane = lane_id;
 						floor_ = 0;
+						if( dbg & 268435456 )		// (ablation: the item's window is laid out and the item dropped)
+							k = -1;
 						t_item = ( dbg & 32 ) ? __builtin_amdgcn_s_memtime() : 0;
 						n_steps = n_emit = 0;
 					}
@@ -952,6 +957,11 @@ rma_drain_kernel( const rmd_program_t *gP, int prog_bytes, DbView db, HitBuf hb,
 		}
 	}
 #undef DRAIN_LAP
+	if( ( dbg & 536870912 ) && lane_id == 0 ){
+		const unsigned long long	t0 = ~__hip_atomic_load( hb.ticket + 55, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+		const unsigned long long	dt = wall_clock64() - t0;		// (100 MHz)
+		atomicAdd( hb.ticket + 23 + rmd_imin( int( dt / 1600 ), 31 ), 1ull );
+	}
 }
 
 // ---------------------------------------------------------------- search kernel
@@ -2105,6 +2115,15 @@ rma_search_kernel( const rmd_program_t *gP, int prog_bytes, int qcap, DbView db,
 											ok = true;
 										else{
 											unsigned long long	Wd = rows_win( pb, pb_words, tile, p_lo, H.minlen, lim, ( H.ends & RMA_5PAIRED ) != 0, s5, w0, bot );
+											if( !( dbg & 134217728 ) ){
+												// ... of which the walk takes only those that leave the groups behind the helix their room and let
+												// them reach the interior's end (rmd_lean_open, rmd_lean_step: rem_min, rem_max): bit i = end w0 + i
+												const int	e_hi = rmd_imin( top, b - H.rem_min ) - w0, e_lo = ( H.rem_max >= 0 ? rmd_imax( bot, b - H.rem_max ) : bot ) - w0;
+												if( e_hi < 63 )
+													Wd &= e_hi < 0 ? 0ull : ( 2ull << e_hi ) - 1;
+												if( e_lo > 0 )
+													Wd &= e_lo > 63 ? 0ull : ~0ull << e_lo;
+											}
 											if( Wd && head_next ){
 												// ... and one of those ends must have the next stem-loop's core at the right distance
 												// behind it (bit i of Wd: end w0 + i)

@@ -1153,6 +1153,15 @@ static void debug_report( rma_scanner_t *sc, unsigned long long count )
 		fprintf( stderr, "[dbg] workgroups that had tiles (%.0f of %d): out of tiles after %.1f us (mean), done after %.1f us (mean), %.1f us (last)\n", g, f.grid,
 			( double( tl[ 2 ] ) / g - t0 ) * 0.01, ( double( tl[ 4 ] ) / g - t0 ) * 0.01, ( double( tl[ 3 ] ) - t0 ) * 0.01 );
 	}
+	if( ( dbg & 536870912 ) && sc->drained ){
+		unsigned long long	bins[ 32 ];
+		( void )hipMemcpy( bins, sc->d_counters + 1 + 23, sizeof( bins ), hipMemcpyDeviceToHost );
+		fprintf( stderr, "[dbg] drain: waves through by 16 us from the first wave's start:" );
+		for( int b = 0; b < 32; b++ )
+			if( bins[ b ] )
+				fprintf( stderr, " %d:%llu", b, bins[ b ] );
+		fprintf( stderr, "\n" );
+	}
 	if( dbg & 32 ){
 		unsigned long long	ph[ 6 ];
 		( void )hipMemcpy( ph, sc->d_counters + 4, sizeof( ph ), hipMemcpyDeviceToHost );
