@@ -19,13 +19,19 @@ from bench import kernel_hash
 with open(dst + "_meta.json", "w") as out:
     json.dump({"kernel_hash": kernel_hash(), "source": src}, out)
     out.write("\n")
-for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+def newest(pattern):
+    """(gpurun merges every call's files into gpurun_out/: a directory collected twice holds both runs' files)"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     shutil.copy(f, dst + "_kernel_stats.csv")
 with open(dst + "_pmc_summary.csv", "w") as out:
     w = csv.writer(out)
     w.writerow(["pass", "kernel", "counter", "dispatches", "mean_per_dispatch"])
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
