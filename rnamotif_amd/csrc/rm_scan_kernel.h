@@ -638,8 +638,13 @@ __device__ PASS_B_ATTR void general_pass_b( const GenTile gt, DevSink sink )
 							}
 						}
 					}
-					if( __ballot( k >= 0 ) == 0 )
+					if( __ballot( k >= 0 ) == 0 ){
+						// (tiles over a concatenation: the items a round popped may all belong to no entry -- starts in the padding
+						// between two entries come one after the other in the queue; only lanes that found the queue empty are done)
+						if( CONCAT && __ballot( !dry ) != 0 )
+							continue;
 						break;
+					}
 					if( dbg & 32 ){
 						// diagnostic: per search level, wave rounds with a lane on it and lanes served
 						for( int kk = 0; kk < P->n_searches; kk++ ){

@@ -5,6 +5,8 @@ and a small work queue).  Run on the GPU box from the repository root:
     python tests/fuzz_campaign.py lean 160 3000 ; python tests/fuzz_campaign.py general 40 3000
     python tests/fuzz_campaign.py grouped 160 3000     (lean descriptors, database cut into short
                                                         entries, groups of small tiles forced)
+    python tests/fuzz_campaign.py concat 160 3000      (... tiles over the concatenation of the entries forced)
+    RNAMOTIF_FLUSH=1 python tests/fuzz_campaign.py lean 160 3000     (the search kernel that walks nothing, whatever the descriptor)
 
 Round 1: 6400 lean, 5700 general and 3566 grouped descriptors, no mismatch.
 Round 3 (drain kernel, order words from the walk's choices, start positions by words): 1173 lean (seeds
@@ -14,7 +16,12 @@ Round 3 (drain kernel, order words from the walk's choices, start positions by w
 instances too): 1788 lean (20000-21821), 1751 lean through the list (30000-31796), 4943 general (6000-12000),
 404 grouped (9000-9407): no mismatch.  After the groups got the word-wise start positions: 2386 grouped
 (15000-17447) and 518 lean (40000-40524): no mismatch.  General instances at three waves per SIMD: 3987 general
-(12000-16796): no mismatch."""
+(12000-16796): no mismatch.
+Round 4 (the search kernel that walks nothing, tickets for four tiles, tiles over the concatenation of the entries): 3250
+lean with RNAMOTIF_FLUSH=1 (50000-53323) and 798 lean (60000-60804): no mismatch; 3341 concat with RNAMOTIF_FLUSH=1
+(50000-53421): ELEVEN mismatches, all general descriptors -- general_pass_b ended a tile's search when a round's 64 popped
+items all lay in the padding between entries (fixed; tests/test_gpu_parity.py::test_concatenation_tiles_items_in_the_padding
+keeps four of them); 3603 general (20000-24340), 2102 grouped (20000-22137): no mismatch.  After the fix: see DESIGN.md section 2."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -25,7 +32,7 @@ kind, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 bad = ran = 0
 t0 = time.time()
 for seed in range(lo, hi):
-    lean = kind in ("lean", "grouped")
+    lean = kind in ("lean", "grouped", "concat")
     rng = np.random.default_rng((1000 if lean else 5000) + seed)
     text = T._random_descriptor(rng) if lean else T._random_general_descriptor(rng)
     open("/tmp/f.descr", "w").write(text)
@@ -40,16 +47,16 @@ for seed in range(lo, hi):
         continue
     s = T._planted_sequence(rng, 6000)
     seqs = [s, s[:301], s[:d.maxlen], s[:d.minlen]]
-    if kind == "grouped":
+    if kind in ("grouped", "concat"):
         cuts = np.sort(rng.integers(0, len(s), size=int(rng.integers(5, 40))))
         seqs = [s[a:b] for a, b in zip(np.r_[0, cuts], np.r_[cuts, len(s)])] + [s[:1030], s[:1024 + d.maxlen], b""]
-        os.environ["RNAMOTIF_SHORT"] = "1"
+        os.environ["RNAMOTIF_SHORT"] = "1" if kind == "grouped" else "2"      # (concat: tiles over the concatenation of the entries)
     want = oracle_scan(d, seqs)
     if want.shape[0] > 300000:
         continue
     if seed % 3 == 0:
         os.environ["RNAMOTIF_TILE"] = "512"; os.environ["RNAMOTIF_QCAP"] = "128"
-        if kind == "grouped":
+        if kind in ("grouped", "concat"):
             os.environ.pop("RNAMOTIF_TILE")     # (a forced tile size switches the groups off)
             os.environ["RNAMOTIF_QCAP"] = "64"
         # the queue's spill area: the default, or one of 16 items (then the rest is searched in place)

@@ -323,6 +323,31 @@ def test_grouped_tiles_agree(built, workdir, gbrna, name):
             assert want.shape == res[0].shape and np.array_equal(want, res[0])
 
 
+@pytest.mark.parametrize("seed", [52490, 50964, 53200, 50360])
+def test_concatenation_tiles_items_in_the_padding(built, tmp_path, seed):
+    """Found by tests/fuzz_campaign.py `concat` (round 4): a general instance over tiles that lie over the concatenation of the
+    entries pops its items 64 at a time and brings each to its entry; starts in the padding between two entries belong to
+    none, and they stand one after the other in the queue -- a round whose items ALL fell out ended the tile's search
+    (general_pass_b: `no lane has work` is not `no lane can get any`).  The campaign's descriptors and databases, as they were."""
+    import rnamotif_amd as R
+    from oracle_binding import oracle_scan
+    rng = np.random.default_rng(1000 + seed)
+    text = _random_descriptor(rng)
+    path = tmp_path / "f.descr"
+    path.write_text(text)
+    d = R.Descriptor(["-descr", str(path)])
+    s = _planted_sequence(rng, 6000)
+    cuts = np.sort(rng.integers(0, len(s), size=int(rng.integers(5, 40))))
+    seqs = [s[a:b] for a, b in zip(np.r_[0, cuts], np.r_[cuts, len(s)])] + [s[:1030], s[:1024 + d.maxlen], b""]
+    want = oracle_scan(d, seqs)
+    assert want.shape[0] > 0
+    for short in ("2", "0"):
+        with _env(RNAMOTIF_SHORT=short):
+            sc = R.Scanner(d)
+            got = sc.scan(sc.database(seqs))
+        assert got.shape == want.shape and np.array_equal(got, want), (short, text)
+
+
 SYN10M_FIRST_TRNA = (b"syn0000         1.981  -12.300 0   59767   82 cgagcc tt ctt taca gag a catg acggaac catg "
                      b"caatccggcaccggagtgaga aggct gttgggc agtct ggcttg catg")
 
