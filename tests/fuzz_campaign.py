@@ -7,6 +7,7 @@ and a small work queue).  Run on the GPU box from the repository root:
                                                         entries, groups of small tiles forced)
     python tests/fuzz_campaign.py concat 160 3000      (... tiles over the concatenation of the entries forced)
     RNAMOTIF_FLUSH=1 python tests/fuzz_campaign.py lean 160 3000     (the search kernel that walks nothing, whatever the descriptor)
+    FUZZ_LOWC=1 python tests/fuzz_campaign.py lean 160 3000          (low-complexity sequence: clustered survivors, overflowing queues)
 
 Round 1: 6400 lean, 5700 general and 3566 grouped descriptors, no mismatch.
 Round 3 (drain kernel, order words from the walk's choices, start positions by words): 1173 lean (seeds
@@ -21,7 +22,10 @@ Round 4 (the search kernel that walks nothing, tickets for four tiles, tiles ove
 lean with RNAMOTIF_FLUSH=1 (50000-53323) and 798 lean (60000-60804): no mismatch; 3341 concat with RNAMOTIF_FLUSH=1
 (50000-53421): ELEVEN mismatches, all general descriptors -- general_pass_b ended a tile's search when a round's 64 popped
 items all lay in the padding between entries (fixed; tests/test_gpu_parity.py::test_concatenation_tiles_items_in_the_padding
-keeps four of them); 3603 general (20000-24340), 2102 grouped (20000-22137): no mismatch.  After the fix: see DESIGN.md section 2."""
+keeps four of them); 3603 general (20000-24340), 2102 grouped (20000-22137): no mismatch.  After the fix: 3116 + 2886
+concat (50000-53189 with RNAMOTIF_FLUSH=1, 70000-72950) and 2337 general (30000-32836): no mismatch.  Low-complexity sequence
+(FUZZ_LOWC=1, RNAMOTIF_FLUSH=1): 266 lean (80000-80296), no mismatch -- and slow: where a window of repeats gives one start
+position a walk that takes the oracle twenty seconds, it takes one wave of the drain kernel minutes."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -46,6 +50,22 @@ for seed in range(lo, hi):
     if d.maxlen > (400 if lean else 160):
         continue
     s = T._planted_sequence(rng, 6000)
+    if os.environ.get("FUZZ_LOWC"):
+        # low-complexity sequence: runs of short repeats with a few point changes between planted stretches -- the filters'
+        # survivors come in clusters, queues and lists overflow
+        lut = np.frombuffer(b"acgt", dtype=np.uint8)
+        parts, n = [], 0
+        while n < 6000:
+            if rng.random() < 0.3:
+                a = int(rng.integers(0, 5800)); piece = s[a:a + int(rng.integers(50, 200))]
+            else:
+                unit = lut[rng.integers(0, 4, size=int(rng.integers(1, 7)))].tobytes()
+                piece = bytearray(unit * int(rng.integers(5, 120)))
+                for _ in range(len(piece) // 25):
+                    piece[int(rng.integers(0, len(piece)))] = int(lut[rng.integers(0, 4)])
+                piece = bytes(piece)
+            parts.append(piece); n += len(piece)
+        s = b"".join(parts)[:6000]
     seqs = [s, s[:301], s[:d.maxlen], s[:d.minlen]]
     if kind in ("grouped", "concat"):
         cuts = np.sort(rng.integers(0, len(s), size=int(rng.integers(5, 40))))
@@ -70,6 +90,8 @@ for seed in range(lo, hi):
         sc = R.Scanner(d)
     except R.RnamotifError:
         continue
+    if os.environ.get("FUZZ_TRACE"):       # (the case at hand, for a run that does not come back)
+        open(os.path.join(ROOT, "gpurun_out", "fuzz_last_%s.descr" % kind), "w").write("# seed %d, %d candidates wanted\n" % (seed, want.shape[0]) + text)
     got = sc.scan(sc.database(seqs))
     ran += 1
     if got.shape != want.shape or not np.array_equal(got, want):
