@@ -6,6 +6,7 @@ and a small work queue).  Run on the GPU box from the repository root:
     python tests/fuzz_campaign.py grouped 160 3000     (lean descriptors, database cut into short
                                                         entries, groups of small tiles forced)
     python tests/fuzz_campaign.py concat 160 3000      (... tiles over the concatenation of the entries forced)
+    python tests/fuzz_campaign.py gconcat 160 3000     (general descriptors over such tiles)
     RNAMOTIF_FLUSH=1 python tests/fuzz_campaign.py lean 160 3000     (the search kernel that walks nothing, whatever the descriptor)
     FUZZ_LOWC=1 python tests/fuzz_campaign.py lean 160 3000          (low-complexity sequence: clustered survivors, overflowing queues)
 
@@ -23,7 +24,7 @@ lean with RNAMOTIF_FLUSH=1 (50000-53323) and 798 lean (60000-60804): no mismatch
 (50000-53421): ELEVEN mismatches, all general descriptors -- general_pass_b ended a tile's search when a round's 64 popped
 items all lay in the padding between entries (fixed; tests/test_gpu_parity.py::test_concatenation_tiles_items_in_the_padding
 keeps four of them); 3603 general (20000-24340), 2102 grouped (20000-22137): no mismatch.  After the fix: 3116 + 2886
-concat (50000-53189 with RNAMOTIF_FLUSH=1, 70000-72950) and 2337 general (30000-32836): no mismatch.  Low-complexity sequence
+concat (50000-53189 with RNAMOTIF_FLUSH=1, 70000-72950), 2337 general (30000-32836) and 3263 gconcat (20000-23940): no mismatch.  Low-complexity sequence
 (FUZZ_LOWC=1, RNAMOTIF_FLUSH=1): 266 lean (80000-80296), no mismatch -- and slow: where a window of repeats gives one start
 position a walk that takes the oracle twenty seconds, it takes one wave of the drain kernel minutes."""
 import os, sys, time
@@ -67,7 +68,7 @@ for seed in range(lo, hi):
             parts.append(piece); n += len(piece)
         s = b"".join(parts)[:6000]
     seqs = [s, s[:301], s[:d.maxlen], s[:d.minlen]]
-    if kind in ("grouped", "concat"):
+    if kind in ("grouped", "concat", "gconcat"):
         cuts = np.sort(rng.integers(0, len(s), size=int(rng.integers(5, 40))))
         seqs = [s[a:b] for a, b in zip(np.r_[0, cuts], np.r_[cuts, len(s)])] + [s[:1030], s[:1024 + d.maxlen], b""]
         os.environ["RNAMOTIF_SHORT"] = "1" if kind == "grouped" else "2"      # (concat: tiles over the concatenation of the entries)
@@ -76,7 +77,7 @@ for seed in range(lo, hi):
         continue
     if seed % 3 == 0:
         os.environ["RNAMOTIF_TILE"] = "512"; os.environ["RNAMOTIF_QCAP"] = "128"
-        if kind in ("grouped", "concat"):
+        if kind in ("grouped", "concat", "gconcat"):
             os.environ.pop("RNAMOTIF_TILE")     # (a forced tile size switches the groups off)
             os.environ["RNAMOTIF_QCAP"] = "64"
         # the queue's spill area: the default, or one of 16 items (then the rest is searched in place)
