@@ -966,6 +966,14 @@ static const Layout *layout_for( rma_scanner_t *sc, const rma_db_t *cdb, char *e
 		}
 	}
 	const int	strands = sc->prog.chk_both_strs ? 2 : 1, dminlen = sc->prog.dminlen;
+	// A general instance's tile is one wave's, walks and all, for milliseconds: a database of fewer tiles than the device
+	// holds workgroups (eight a CU) gets smaller ones -- down to 256 positions -- so that a short database, or one heavy
+	// region of it, is not the work of a handful of waves (a 6 000 base database of repeats: 3 tiles, 90 s).
+	if( !sc->dprog.lean_ok && group == 1 && sc->opt.tile == 0 ){
+		const int64_t	positions = ( concat ? db->padded_bases : db->sum_slen ) * strands, slots = sc->grid_blocks;
+		if( positions / tile_t < slots )
+			tile_t = int( std::min<int64_t>( tile_t, std::max<int64_t>( 256, ( positions / slots + 63 ) / 64 * 64 ) ) );
+	}
 	std::lock_guard<std::mutex>	lk( db->mu );
 	for( auto &l : db->layouts )
 		if( l->tile_t == tile_t && l->dminlen == dminlen && l->strands == strands && l->group == group && l->qcap == qcap && l->concat == concat && l->flush == flush )
