@@ -25,8 +25,8 @@ lean with RNAMOTIF_FLUSH=1 (50000-53323) and 798 lean (60000-60804): no mismatch
 items all lay in the padding between entries (fixed; tests/test_gpu_parity.py::test_concatenation_tiles_items_in_the_padding
 keeps four of them); 3603 general (20000-24340), 2102 grouped (20000-22137): no mismatch.  After the fix: 3116 + 2886
 concat (50000-53189 with RNAMOTIF_FLUSH=1, 70000-72950), 2337 general (30000-32836) and 3263 gconcat (20000-23940): no mismatch.  Low-complexity sequence
-(FUZZ_LOWC=1, RNAMOTIF_FLUSH=1): 266 lean (80000-80296), no mismatch -- and slow in places: seed 80277, a descriptor that
-begins with a single strand, takes the oracle ten seconds and the device eighty."""
+(FUZZ_LOWC=1, RNAMOTIF_FLUSH=1): 266 lean (80000-80296), no mismatch -- and slow in places: seed 80277, a general
+descriptor over runs of repeats, takes the oracle ten seconds and the device eighty (profiles/lowc_case.py)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
